@@ -1,0 +1,97 @@
+"""ctypes loader for the plain-C oracle (TEST INFRASTRUCTURE ONLY)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+POINTWISE_KINDS = {
+    "slater": 0, "vwn5": 1, "vwn_rpa": 2, "pw92": 3, "pbe_x": 4, "pbe_c": 5,
+    "b88": 6, "lyp": 7, "lda": 8, "gga": 9, "b3lyp": 10,
+}
+
+
+def build(omp=False):
+    """Compile the oracle with gcc (idempotent: make decides)."""
+    target = "_build/liboracle_omp.so" if omp else "_build/liboracle.so"
+    subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
+    return os.path.join(_HERE, target)
+
+
+def lib(omp=False):
+    key = bool(omp)
+    if key not in _LIBS:
+        path = os.path.join(_HERE, "_build", "liboracle_omp.so" if omp else "liboracle.so")
+        if not os.path.exists(path) or any(
+            os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(path)
+            for s in ("xc_oracle.c", "ao_oracle.c")
+        ):
+            path = build(omp)
+        L = ctypes.CDLL(path)
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.orc_compute_xc.restype = ctypes.c_double
+        L.orc_compute_xc.argtypes = [ctypes.c_int, ctypes.c_long, ctypes.c_int, dp, dp, dp, dp,
+                                     dp, ctypes.c_int, dp, dp]
+        L.orc_coulomb.restype = None
+        L.orc_coulomb.argtypes = [ctypes.c_int, dp, dp, dp]
+        L.orc_exchange.restype = None
+        L.orc_exchange.argtypes = [ctypes.c_int, dp, dp, dp]
+        L.orc_pointwise.restype = None
+        L.orc_pointwise.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long, dp, dp, dp]
+        _LIBS[key] = L
+    return _LIBS[key]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _c(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def compute_xc(xc_type, dm, ao, weights, ao_grad=None, quirks=True, want_density=False, omp=False):
+    """Oracle of DFT_ComputeXC.  xc_type 0/1/2 (LDA/GGA/B3LYP).
+    Returns (exc, vxc_raw[, rho, grad_rho])."""
+    ao = _c(ao); dm = _c(dm); w = _c(weights); gr = _c(ao_grad)
+    ngrid, nao = ao.shape
+    assert dm.shape == (nao, nao) and w.shape == (ngrid,)
+    if xc_type != 0:
+        assert gr is not None and gr.shape == (3, ngrid, nao)
+    vxc = np.zeros((nao, nao))
+    rho = np.zeros(ngrid) if want_density else None
+    grad = np.zeros((ngrid, 3)) if want_density else None
+    exc = lib(omp).orc_compute_xc(int(xc_type), ngrid, nao, _p(dm), _p(ao), _p(gr), _p(w),
+                                  _p(vxc), 1 if quirks else 0, _p(rho), _p(grad))
+    if want_density:
+        return exc, vxc, rho, grad
+    return exc, vxc
+
+
+def coulomb(eri, dm):
+    dm = _c(dm); nao = dm.shape[0]
+    eri = _c(eri).reshape(nao * nao, nao * nao)
+    J = np.zeros((nao, nao))
+    lib().orc_coulomb(nao, _p(eri), _p(dm), _p(J))
+    return J
+
+
+def exchange(eri, dm):
+    dm = _c(dm); nao = dm.shape[0]
+    eri = _c(eri).reshape(nao * nao, nao * nao)
+    K = np.zeros((nao, nao))
+    lib().orc_exchange(nao, _p(eri), _p(dm), _p(K))
+    return K
+
+
+def pointwise(kind, rho, sigma=None, quirks=True):
+    """(n,3) array of (e, vrho, vsigma) for one functional kind (name or id)."""
+    k = POINTWISE_KINDS[kind] if isinstance(kind, str) else int(kind)
+    rho = _c(np.atleast_1d(rho))
+    sigma = _c(np.atleast_1d(sigma)) if sigma is not None else np.zeros_like(rho)
+    out = np.zeros((rho.size, 3))
+    lib().orc_pointwise(k, 1 if quirks else 0, rho.size, _p(rho), _p(sigma), _p(out))
+    return out
