@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the XC sweep (DFT_ComputeXC) on MI355X.
+
+python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Step   = one DFT_ComputeXC call on one batch of synthetic AO/grid data resident in HBM
+         (the bracket the reference times at dft.py:205-208: call + device sync), followed for
+         N>1 by the RCCL all-reduce of [Vxc | Exc] over the grid shards.
+Work   = BASELINE.json's metric config: Benzene GGA(PBE) def2-SVP shape (nao 114, ngrid 143 556)
+         per GPU (weak scaling: every rank owns a full-size grid shard).
+Output = ONE JSON line on rank 0 (metric grid-points/s) carrying `roofline` for the dominant
+         kernel (HIP-event timed on the solver's stream) and `cpu_baseline` (the OpenMP build of
+         the CPU oracle timed on a bounded slice of the same inputs; N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import quantum_compute_dft_amd as q  # noqa: E402
+
+WORKLOADS = {
+    # name: (functional, nao, ngrid)   sizes from SURVEY.md section 8
+    "benzene_gga_def2svp": ("GGA", 114, 143556),
+    "h2o_lda_def2svp": ("LDA", 24, 34310),
+    "anthracene_b3lyp_def2tzvp": ("B3LYP", 494, 294868),
+    "anthracene_b3lyp_sto3g": ("B3LYP", 80, 294868),
+}
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F64_MFMA_PEAK_TF = 78.6      # AMD datasheet fp64 matrix peak (the local guide lists no fp64 figure)
+SEED = 20260128
+
+
+def synth(ngrid, nao, need_grad, dev, seed):
+    """SURVEY 8(d) recipe, generated on the device: ao=0.4 N, grad=0.3 N, w=0.05 U, dm=2CC^T."""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    ao = 0.4 * torch.randn((ngrid, nao), dtype=torch.float64, device=dev, generator=g)
+    gr = 0.3 * torch.randn((3, ngrid, nao), dtype=torch.float64, device=dev, generator=g) if need_grad else None
+    w = 0.05 * torch.rand((ngrid,), dtype=torch.float64, device=dev, generator=g)
+    nocc = -(-nao // 5)
+    C = 0.7 * torch.randn((nao, nocc), dtype=torch.float64, device=dev, generator=g)
+    dm = 2.0 * C @ C.T
+    return dm.contiguous(), ao, gr, w
+
+
+def kernel_model(name, xc, ngrid, nao):
+    """Algorithmic bytes and flops of one launch (B = ngrid*(8*nao*c+8)+16*nao^2,
+    F = 4*ngrid*nao^2 + (2c+8[c=4])*ngrid*nao for the whole sweep; each of the two contraction
+    kernels streams the c AO planes once and does half of the GEMM flops)."""
+    c = 1 if xc == "LDA" else 4
+    planes = 8.0 * ngrid * nao * c
+    if name == "rho":
+        return planes + 8.0 * nao * nao + 8.0 * ngrid * c, 2.0 * ngrid * nao * nao + 2.0 * c * ngrid * nao
+    if name == "vxc":
+        return planes + 8.0 * ngrid * c + 8.0 * nao * nao, 2.0 * ngrid * nao * nao + 2.0 * c * ngrid * nao
+    if name == "xc_sweep":  # fused single kernel
+        return planes + 8.0 * ngrid + 16.0 * nao * nao, 4.0 * ngrid * nao * nao + (2 * c + (8 if c == 4 else 0)) * ngrid * nao
+    if name == "xc_points":
+        return 8.0 * ngrid * (2 + 2 * c), 0.0
+    return 0.0, 0.0
+
+
+def cpu_baseline(xc, dm, ao, gr, w, sample):
+    import oracle                                   # test infrastructure: the checker, timed as the baseline
+    threads = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    oracle.build(omp=True)
+    t = {"LDA": 0, "GGA": 1, "B3LYP": 2}[xc]
+    h = lambda a: None if a is None else a.cpu().numpy()
+    dm_h, ao_h, w_h = h(dm), h(ao[:sample]), h(w[:sample])
+    gr_h = None if gr is None else np.ascontiguousarray(h(gr[:, :sample]))
+    oracle.compute_xc(t, dm_h, ao_h[:256], w_h[:256], None if gr_h is None else gr_h[:, :256], omp=True)  # warm
+    t0 = time.perf_counter()
+    oracle.compute_xc(t, dm_h, ao_h, w_h, gr_h, omp=True)
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "grid-points/s", "cores": int(os.environ["OMP_NUM_THREADS"]),
+            "kind": "port", "seconds": dt,
+            "sample": f"first {sample} grid points of the same inputs, OpenMP build of oracle/xc_oracle.c "
+                      f"(reference loop structure, dft_solver.cu:346-432)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="benzene_gga_def2svp", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample", type=int, default=16384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    xc, nao, ngrid = WORKLOADS[args.workload]
+    dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)   # dm identical on all ranks
+    if world > 1:
+        dist.broadcast(dm, 0)
+    solver = q.DFTSolverWrapper(q.build_library(), xc)
+    out = torch.zeros(nao * nao + 1, dtype=torch.float64, device=dev)   # [Vxc | Exc]
+    d_v, d_e = out[: nao * nao], out[nao * nao:]
+
+    def step():
+        if world == 1:
+            return solver.compute_xc(ngrid, nao, dm, ao, w, d_v, gr)    # synchronous, returns Exc
+        solver.compute_xc_async(ngrid, nao, dm, ao, w, d_v, d_e, gr)
+        dist.all_reduce(out)                                            # sum of the shard partials
+        return float(d_e.item())                                        # device sync, like the ABI call
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        exc = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        exc = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # per-kernel durations: HIP events recorded by the library on its own stream, same steps
+    solver.set_option("profile", 1)
+    acc = {}
+    for _ in range(args.steps):
+        solver.compute_xc(ngrid, nao, dm, ao, w, d_v, gr)
+        for name, ms in solver.timings():
+            acc.setdefault(name, []).append(ms)
+    solver.set_option("profile", 0)
+    kern = {k: float(np.mean(v)) for k, v in acc.items()}
+
+    if rank == 0:
+        dom = max(kern, key=kern.get)
+        b_alg, f_alg = kernel_model(dom, xc, ngrid, nao)
+        t_dom = kern[dom] * 1e-3
+        hbm_t, mfma_t = b_alg / (HBM_PEAK_GBS * 1e9), f_alg / (F64_MFMA_PEAK_TF * 1e12)
+        if hbm_t >= mfma_t:
+            roof = {"bound": "hbm", "achieved": b_alg / t_dom / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        else:
+            roof = {"bound": "mfma", "achieved": f_alg / t_dom / 1e12, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof.update({"kernel": dom, "kernel_ms": kern[dom], "alg_bytes": b_alg, "alg_flops": f_alg,
+                     "other_bound_frac": (f_alg / t_dom / 1e12 / F64_MFMA_PEAK_TF) if roof["bound"] == "hbm"
+                     else (b_alg / t_dom / 1e9 / HBM_PEAK_GBS)})
+        b_all, f_all = kernel_model("xc_sweep", xc, ngrid, nao)
+        line = {
+            "metric": "grid_points_per_sec", "value": world * ngrid * args.steps / dt, "unit": "grid-points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: DFT_ComputeXC ({xc}) nao={nao} ngrid={ngrid} per GPU, "
+                                   f"synthetic AO/grid (SURVEY 8(d) recipe), inputs resident in HBM",
+                       "functional": xc, "nao": nao, "ngrid_per_gpu": ngrid,
+                       "sharding": "grid points" + ("" if world == 1 else f" x{world}, RCCL all-reduce of Vxc|Exc")},
+            "roofline": roof,
+            "sweep": {"alg_bytes": b_all, "alg_flops": f_all,
+                      "hbm_frac_of_step": b_all / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                      "mfma_frac_of_step": f_all / (dt / args.steps) / 1e12 / F64_MFMA_PEAK_TF},
+            "kernels_ms": kern, "exc": exc,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(xc, dm, ao, gr, w, min(args.cpu_sample, ngrid))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+/*
+ * dft_solver.h -- C-ABI of the MI355X-native XC/Fock engine (libdft.so).
+ *
+ * Drop-in boundary: the first four entry points are exactly the four
+ * `extern "C"` symbols of the reference (src/dft_solver.h:66-88, defined at
+ * src/dft_solver.cu:675-719) that its ctypes wrapper binds (dft.py:24-50):
+ * same names, argument order, types and error behaviour.  Everything after
+ * them is a non-breaking extension (new symbols only).
+ *
+ * All pointers are raw *device* addresses passed as 64-bit integers, exactly
+ * as the reference's caller does (`cupy_array.data.ptr`, dft.py:69-95).  All
+ * arrays are fp64, C-contiguous:
+ *   dm (nao,nao) | ao (ngrid,nao) | ao_grad (3,ngrid,nao) planar | weights (ngrid)
+ *   vxc (nao,nao) overwritten | eri (nao^2,nao^2) | J, K (nao,nao) overwritten.
+ * Work is enqueued on the solver's stream (default: the null stream, like the
+ * reference); DFT_ComputeXC is synchronous on return (it returns Exc).
+ * No function throws or aborts; failures print one line to stderr, are
+ * retrievable with DFT_GetLastError(), and make DFT_ComputeXC return NaN.
+ */
+#ifndef QCDFT_AMD_DFT_SOLVER_H
+#define QCDFT_AMD_DFT_SOLVER_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Opaque handle; replaces the reference's `class XCSolver` hierarchy
+ * (src/dft_solver.h:7-63: XCSolver / LDASolver / GGASolver / B3LYPSolver). */
+typedef struct XCSolver XCSolver;
+
+/* src/dft_solver.h:67-71 */
+enum SolverType { SOLVER_LDA = 0, SOLVER_GGA = 1, SOLVER_B3LYP = 2 };
+
+/* ---- reference ABI ------------------------------------------------------ */
+
+/* src/dft_solver.h:73, src/dft_solver.cu:677-682.  Unknown type -> NULL. */
+XCSolver *DFT_CreateSolver(int type);
+
+/* src/dft_solver.h:75, src/dft_solver.cu:684-686.  NULL is a no-op. */
+void DFT_DestroySolver(XCSolver *solver);
+
+/* src/dft_solver.h:77-82, src/dft_solver.cu:688-704 -> {LDA,GGA,B3LYP}Solver::
+ * compute_xc (:559-672).  Returns Exc = sum_g w_g rho_g eps_xc(g) and
+ * overwrites vxc:  LDA/B3LYP symmetric; GGA the reference's one-sided matrix
+ * (the caller averages it, dft.py:212).  d_ao_grad_ptr may be 0 for LDA.
+ * NULL solver -> 0.0 (src/dft_solver.cu:695). */
+double DFT_ComputeXC(XCSolver *solver, int ngrid, int nao,
+                     unsigned long long d_dm_ptr,
+                     unsigned long long d_ao_ptr,
+                     unsigned long long d_ao_grad_ptr,
+                     unsigned long long d_weights_ptr,
+                     unsigned long long d_vxc_ptr);
+
+/* src/dft_solver.h:84-87, src/dft_solver.cu:706-718 -> XCSolver::
+ * compute_coulomb (:550-555).  J.ravel() = ERI^T . D.ravel() (the cublasDgemv
+ * OP_N call on the row-major buffer).  Asynchronous on the solver's stream.
+ * NULL solver -> no-op (src/dft_solver.cu:711). */
+void DFT_ComputeCoulomb(XCSolver *solver, int nao,
+                        unsigned long long d_eri_ptr,
+                        unsigned long long d_dm_ptr,
+                        unsigned long long d_J_ptr);
+
+/* ---- extensions (not in the reference) ---------------------------------- */
+
+/* ABI version of this library (bumped when an extension changes). */
+int DFT_GetVersion(void);
+
+/* Same as DFT_ComputeXC with a 64-bit grid count (the reference's `int`
+ * products overflow once ngrid*nao >= 2^30, src/dft_solver.cu:597,634). */
+double DFT_ComputeXC64(XCSolver *solver, long long ngrid, int nao,
+                       unsigned long long d_dm_ptr,
+                       unsigned long long d_ao_ptr,
+                       unsigned long long d_ao_grad_ptr,
+                       unsigned long long d_weights_ptr,
+                       unsigned long long d_vxc_ptr);
+
+/* Asynchronous form: Exc is written to the device double at d_exc_ptr; no
+ * host synchronisation.  Returns 0 on success. */
+int DFT_ComputeXCAsync(XCSolver *solver, long long ngrid, int nao,
+                       unsigned long long d_dm_ptr,
+                       unsigned long long d_ao_ptr,
+                       unsigned long long d_ao_grad_ptr,
+                       unsigned long long d_weights_ptr,
+                       unsigned long long d_vxc_ptr,
+                       unsigned long long d_exc_ptr);
+
+/* Exact exchange on the dense ERI, replaces the driver's
+ * cp.einsum('ijkl,jl->ik', eri4d, dm) (dft.py:218).  Asynchronous. */
+void DFT_ComputeExchange(XCSolver *solver, int nao,
+                         unsigned long long d_eri_ptr,
+                         unsigned long long d_dm_ptr,
+                         unsigned long long d_K_ptr);
+
+/* J and K from ONE pass over the dense ERI (dft.py:203 + dft.py:218).
+ * Either output pointer may be 0. */
+void DFT_ComputeJK(XCSolver *solver, int nao,
+                   unsigned long long d_eri_ptr,
+                   unsigned long long d_dm_ptr,
+                   unsigned long long d_J_ptr,
+                   unsigned long long d_K_ptr);
+
+/* AO values (and Cartesian gradients) on the grid: replaces PySCF's
+ * dft.numint.eval_ao(mol, coords, deriv=0/1) at grid.py:30,38.
+ * Shell table (host pointers, copied to the device on first use / change):
+ *   nshell shells; shell s: centre (x,y,z) bohr in shl_xyz[3s..], angular
+ *   momentum shl_l[s] (0..3), shl_nprim[s] primitives starting at
+ *   shl_off[s] in prim_exp / prim_coef (coefficients already include the
+ *   primitive and contraction normalisation), first AO column shl_ao[s].
+ * coords (ngrid,3) device; ao (ngrid,nao) device out; ao_grad (3,ngrid,nao)
+ * device out or 0.  Returns 0 on success. */
+int DFT_EvalAO(XCSolver *solver, long long ngrid, int nao, int nshell,
+               const double *shl_xyz, const int *shl_l, const int *shl_nprim,
+               const int *shl_off, const int *shl_ao,
+               const double *prim_exp, const double *prim_coef, int nprim_total,
+               unsigned long long d_coords_ptr,
+               unsigned long long d_ao_ptr,
+               unsigned long long d_ao_grad_ptr);
+
+/* Options: "quirks" (1 = reference formulas as shipped, default; 0 = corrected
+ * VWN5 / PBE-c derivatives), "path" (0 = MFMA kernels, default;
+ * 1 = plain-VALU validation kernels), "profile" (1 = record per-kernel HIP
+ * events for DFT_GetTimings), "ksplit" (grid chunks of the Vxc contraction;
+ * 0 = auto).  Returns 0 if the key is known. */
+int DFT_SetOption(XCSolver *solver, const char *key, double value);
+
+/* Run subsequent work on `hip_stream` (a hipStream_t cast to an integer);
+ * 0 restores the null stream. */
+int DFT_SetStream(XCSolver *solver, unsigned long long hip_stream);
+
+/* Last error text ("" if none).  The pointer stays valid until the next call
+ * on the same solver. */
+const char *DFT_GetLastError(XCSolver *solver);
+
+/* With option "profile"=1: durations (ms) of the kernels of the last
+ * DFT_ComputeXC* call, in launch order; names[i] (if non-NULL) receives a
+ * static string.  Returns the number of entries written (<= max_entries). */
+int DFT_GetTimings(XCSolver *solver, double *ms, const char **names, int max_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QCDFT_AMD_DFT_SOLVER_H */

@@ -41,6 +41,10 @@ def lib(omp=False):
         L.orc_exchange.argtypes = [ctypes.c_int, dp, dp, dp]
         L.orc_pointwise.restype = None
         L.orc_pointwise.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_long, dp, dp, dp]
+        ip = ctypes.POINTER(ctypes.c_int)
+        L.orc_eval_ao.restype = ctypes.c_int
+        L.orc_eval_ao.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int, dp, ip, ip, ip, ip,
+                                  dp, dp, dp, dp, dp]
         _LIBS[key] = L
     return _LIBS[key]
 
@@ -95,3 +99,21 @@ def pointwise(kind, rho, sigma=None, quirks=True):
     out = np.zeros((rho.size, 3))
     lib().orc_pointwise(k, 1 if quirks else 0, rho.size, _p(rho), _p(sigma), _p(out))
     return out
+
+
+def eval_ao(shells, coords, deriv=0):
+    """Oracle of DFT_EvalAO.  `shells` needs attributes xyz (nshell,3), l, nprim, off, ao
+    (int arrays), exp, coef (normalised), nao.  Returns ao (ngrid,nao)[, grad (3,ngrid,nao)]."""
+    coords = _c(coords)
+    ngrid = coords.shape[0]
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    ipp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    xyz = _c(shells.xyz); ls = i32(shells.l); npr = i32(shells.nprim); off = i32(shells.off)
+    aoc = i32(shells.ao); ex = _c(shells.exp); cf = _c(shells.coef)
+    ao = np.zeros((ngrid, shells.nao))
+    grad = np.zeros((3, ngrid, shells.nao)) if deriv else None
+    rc = lib().orc_eval_ao(ngrid, shells.nao, len(ls), _p(xyz), ipp(ls), ipp(npr), ipp(off),
+                           ipp(aoc), _p(ex), _p(cf), _p(coords), _p(ao), _p(grad))
+    if rc != 0:
+        raise ValueError("oracle eval_ao: unsupported angular momentum")
+    return (ao, grad) if deriv else ao

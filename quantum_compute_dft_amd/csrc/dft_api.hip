@@ -1,0 +1,451 @@
+// C-ABI of libdft.so (include/dft_solver.h) and the host orchestration behind it.
+//
+// Replaces src/dft_solver.cu:530-719 of the reference (XCSolver classes, the
+// per-call cudaMalloc/cudaFree sequence and the four extern "C" entry points).
+// Differences by design: one persistent workspace per solver instead of 6-7
+// allocations per call; 64-bit index arithmetic; deterministic reductions;
+// errors are recorded (DFT_GetLastError) as well as printed.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/dft_solver.h"
+#include "ao_kernels.hpp"
+#include "jk_kernels.hpp"
+#include "xc_kernels.hpp"
+
+using namespace qcdft;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Timing {
+    const char *name;
+    hipEvent_t t0, t1;
+};
+
+} // namespace
+
+struct XCSolver {
+    int type = 0;
+    hipStream_t stream = nullptr;
+    bool device_ok = false;
+    int num_cu = 256;
+    // options
+    int quirks = 1;
+    int path = 0; // 0 MFMA, 1 VALU validation kernels
+    int profile = 0;
+    int ksplit = 0;
+    // workspace
+    DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells;
+    double *h_exc = nullptr; // pinned
+    std::string last_error;
+    std::vector<Timing> timings;
+    size_t n_timed = 0;
+    // AO shell-table cache key
+    std::vector<unsigned char> shell_blob;
+};
+
+namespace {
+
+void set_error(XCSolver *s, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "libdft: %s\n", buf);
+    if (s) s->last_error = buf;
+}
+
+bool hip_ok(XCSolver *s, hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    set_error(s, "%s failed: %s", what, hipGetErrorString(e));
+    return false;
+}
+
+bool reserve(XCSolver *s, DevBuf &b, size_t bytes, const char *what)
+{
+    if (bytes <= b.cap) return true;
+    if (b.p) {
+        (void)hipStreamSynchronize(s->stream);
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    if (!hip_ok(s, hipMalloc(&b.p, want), what)) return false;
+    b.cap = want;
+    return true;
+}
+
+struct ScopedTimer {
+    XCSolver *s;
+    size_t idx = 0;
+    bool on;
+    ScopedTimer(XCSolver *s_, const char *name) : s(s_), on(s_->profile != 0)
+    {
+        if (!on) return;
+        idx = s->n_timed++;
+        if (idx >= s->timings.size()) {
+            Timing t{name, nullptr, nullptr};
+            (void)hipEventCreate(&t.t0);
+            (void)hipEventCreate(&t.t1);
+            s->timings.push_back(t);
+        }
+        s->timings[idx].name = name;
+        (void)hipEventRecord(s->timings[idx].t0, s->stream);
+    }
+    ~ScopedTimer()
+    {
+        if (on) (void)hipEventRecord(s->timings[idx].t1, s->stream);
+    }
+};
+
+int auto_ksplit(const XCSolver *s, long ngrid, int nblk)
+{
+    if (s->ksplit > 0) return s->ksplit;
+    // enough workgroups to fill the chip a few times over, >= 256 points each
+    long want = (4L * s->num_cu + nblk - 1) / nblk;
+    long maxsplit = (ngrid + 255) / 256;
+    if (want > maxsplit) want = maxsplit;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+// The sweep: everything on s->stream, Exc left in s->exc (device).
+bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *ao,
+              const double *ao_grad, const double *w, double *vxc)
+{
+    s->last_error.clear();
+    s->n_timed = 0;
+    if (!s->device_ok) {
+        set_error(s, "no usable HIP device");
+        return false;
+    }
+    if (ngrid <= 0 || nao <= 0) {
+        set_error(s, "bad sizes ngrid=%ld nao=%d", ngrid, nao);
+        return false;
+    }
+    const bool gga = s->type != SOLVER_LDA;
+    if (gga && !ao_grad) {
+        set_error(s, "ao_grad pointer is null for a gradient-corrected functional");
+        return false;
+    }
+    const int NP = ((nao + 15) / 16) * 16;
+    const int nblk = (nao + 127) / 128;
+    const int nsplit = auto_ksplit(s, ngrid, nblk * nblk);
+    long chunk = (ngrid + nsplit - 1) / nsplit;
+    chunk = ((chunk + 31) / 32) * 32;
+    const int nslab = (int)((ngrid + chunk - 1) / chunk);
+    const long nxb = (ngrid + 255) / 256;
+    const size_t ng = (size_t)ngrid;
+
+    if (!reserve(s, s->dsym, sizeof(double) * NP * NP, "hipMalloc(Dsym)") ||
+        !reserve(s, s->rho, sizeof(double) * ng, "hipMalloc(rho)") ||
+        !reserve(s, s->coef, sizeof(double) * ng * (gga ? 4 : 1), "hipMalloc(coef)") ||
+        !reserve(s, s->partial, sizeof(double) * nxb, "hipMalloc(partial)") ||
+        !reserve(s, s->slabs, sizeof(double) * (size_t)nslab * nao * nao, "hipMalloc(slabs)") ||
+        !reserve(s, s->exc, sizeof(double), "hipMalloc(exc)"))
+        return false;
+    if (gga && (!reserve(s, s->sigma, sizeof(double) * ng, "hipMalloc(sigma)") ||
+                !reserve(s, s->grad, sizeof(double) * 3 * ng, "hipMalloc(grad)")))
+        return false;
+
+    double *Dp = (double *)s->dsym.p, *rho = (double *)s->rho.p, *sigma = (double *)s->sigma.p,
+           *grad = (double *)s->grad.p, *coef = (double *)s->coef.p,
+           *partial = (double *)s->partial.p, *slabs = (double *)s->slabs.p,
+           *exc = (double *)s->exc.p;
+    const double *gx = ao_grad, *gy = gga ? ao_grad + ng * nao : nullptr,
+                 *gz = gga ? ao_grad + 2 * ng * nao : nullptr;
+    hipStream_t st = s->stream;
+
+    {
+        ScopedTimer t(s, "sym_dm");
+        dim3 b(16, 16), g(NP / 16, NP / 16);
+        hipLaunchKernelGGL(k_sym_dm, g, b, 0, st, nao, NP, dm, Dp);
+    }
+    {
+        ScopedTimer t(s, "rho");
+        if (s->path == 0) {
+            dim3 g((unsigned)((ngrid + 63) / 64));
+            if (gga) hipLaunchKernelGGL(k_rho_mfma<true>, g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
+            else     hipLaunchKernelGGL(k_rho_mfma<false>, g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
+        } else {
+            dim3 g((unsigned)((ngrid + 3) / 4));
+            if (gga) hipLaunchKernelGGL(k_rho_valu<true>, g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
+            else     hipLaunchKernelGGL(k_rho_valu<false>, g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
+        }
+    }
+    {
+        ScopedTimer t(s, "xc_points");
+        dim3 g((unsigned)nxb);
+        if (s->type == SOLVER_LDA)      hipLaunchKernelGGL(k_xc_points<0>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
+        else if (s->type == SOLVER_GGA) hipLaunchKernelGGL(k_xc_points<1>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
+        else                            hipLaunchKernelGGL(k_xc_points<2>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, nxb, partial, exc);
+    }
+    {
+        ScopedTimer t(s, "vxc");
+        if (s->path == 0) {
+            dim3 g((unsigned)nslab, nblk, nblk);
+            if (gga) hipLaunchKernelGGL(k_vxc_mfma<true>, g, dim3(256), 0, st, ngrid, nao, chunk, ao, gx, gy, gz, coef, slabs);
+            else     hipLaunchKernelGGL(k_vxc_mfma<false>, g, dim3(256), 0, st, ngrid, nao, chunk, ao, gx, gy, gz, coef, slabs);
+        } else {
+            dim3 g((unsigned)nslab);
+            if (gga) hipLaunchKernelGGL(k_vxc_valu<true>, g, dim3(256), 0, st, ngrid, nao, chunk, ao, gx, gy, gz, coef, slabs);
+            else     hipLaunchKernelGGL(k_vxc_valu<false>, g, dim3(256), 0, st, ngrid, nao, chunk, ao, gx, gy, gz, coef, slabs);
+        }
+    }
+    {
+        ScopedTimer t(s, "reduce_vxc");
+        dim3 g((unsigned)(((size_t)nao * nao + 255) / 256));
+        if (s->type == SOLVER_B3LYP) hipLaunchKernelGGL(k_reduce_slabs<true>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
+        else                         hipLaunchKernelGGL(k_reduce_slabs<false>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
+    }
+    return hip_ok(s, hipGetLastError(), "XC sweep launch");
+}
+
+void jk(XCSolver *s, int nao, const double *eri, const double *dm, double *J, double *K)
+{
+    s->last_error.clear();
+    if (!s->device_ok) { set_error(s, "no usable HIP device"); return; }
+    if (nao <= 0 || nao > JK_COLS) { set_error(s, "dense-ERI J/K needs 1 <= nao <= %d (got %d)", JK_COLS, nao); return; }
+    if (!J && !K) return;
+    const int n = nao;
+    const size_t N2 = (size_t)n * n;
+    const int KB = std::max(1, std::min(n, JK_COLS / n));
+    const int ncb = (n + KB - 1) / KB;
+    // enough workgroups to fill the chip: split the j range when n*ncb is small
+    int jsplit = 1;
+    while ((long)n * ncb * jsplit < 4L * s->num_cu && jsplit * 2 <= n) jsplit *= 2;
+    const int nslabJ = n * jsplit;
+    if (J && !reserve(s, s->jpart, sizeof(double) * nslabJ * N2, "hipMalloc(Jpart)")) return;
+    if (K && !reserve(s, s->kpart, sizeof(double) * jsplit * N2, "hipMalloc(Kpart)")) return;
+    double *jp = (double *)s->jpart.p, *kp = (double *)s->kpart.p;
+    dim3 g(ncb, n * jsplit);
+    hipStream_t st = s->stream;
+    if (J && K)  hipLaunchKernelGGL((k_jk_stream<true, true>), g, dim3(256), 0, st, n, KB, jsplit, eri, dm, jp, kp);
+    else if (J)  hipLaunchKernelGGL((k_jk_stream<true, false>), g, dim3(256), 0, st, n, KB, jsplit, eri, dm, jp, kp);
+    else         hipLaunchKernelGGL((k_jk_stream<false, true>), g, dim3(256), 0, st, n, KB, jsplit, eri, dm, jp, kp);
+    dim3 gr((unsigned)((N2 + 255) / 256));
+    if (J) hipLaunchKernelGGL(k_sum_slabs, gr, dim3(256), 0, st, N2, nslabJ, N2, jp, J);
+    if (K) hipLaunchKernelGGL(k_sum_slabs, gr, dim3(256), 0, st, N2, jsplit, N2, kp, K);
+    hip_ok(s, hipGetLastError(), "J/K launch");
+}
+
+} // namespace
+
+extern "C" {
+
+int DFT_GetVersion(void) { return 1; }
+
+XCSolver *DFT_CreateSolver(int type)
+{
+    if (type != SOLVER_LDA && type != SOLVER_GGA && type != SOLVER_B3LYP) return nullptr;
+    XCSolver *s = new (std::nothrow) XCSolver();
+    if (!s) return nullptr;
+    s->type = type;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            s->device_ok = true;
+            s->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        if (s->device_ok && hipHostMalloc((void **)&s->h_exc, sizeof(double)) != hipSuccess) {
+            s->h_exc = nullptr;
+        }
+    } else {
+        (void)hipGetLastError();
+        s->last_error = "no usable HIP device";
+    }
+    return s;
+}
+
+void DFT_DestroySolver(XCSolver *s)
+{
+    if (!s) return;
+    if (s->device_ok) {
+        (void)hipStreamSynchronize(s->stream);
+        DevBuf *bufs[] = {&s->dsym, &s->rho, &s->sigma, &s->grad, &s->coef, &s->partial,
+                          &s->slabs, &s->exc, &s->jpart, &s->kpart, &s->shells};
+        for (DevBuf *b : bufs)
+            if (b->p) (void)hipFree(b->p);
+        if (s->h_exc) (void)hipHostFree(s->h_exc);
+        for (Timing &t : s->timings) {
+            (void)hipEventDestroy(t.t0);
+            (void)hipEventDestroy(t.t1);
+        }
+    }
+    delete s;
+}
+
+double DFT_ComputeXC64(XCSolver *s, long long ngrid, int nao, unsigned long long d_dm,
+                       unsigned long long d_ao, unsigned long long d_ao_grad,
+                       unsigned long long d_w, unsigned long long d_vxc)
+{
+    if (!s) return 0.0;
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    if (!xc_sweep(s, (long)ngrid, nao, (const double *)d_dm, (const double *)d_ao,
+                  (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc))
+        return nan;
+    double out = nan;
+    double *dst = s->h_exc ? s->h_exc : &out;
+    if (!hip_ok(s, hipMemcpyAsync(dst, s->exc.p, sizeof(double), hipMemcpyDeviceToHost, s->stream), "copy Exc") ||
+        !hip_ok(s, hipStreamSynchronize(s->stream), "synchronise"))
+        return nan;
+    return *dst;
+}
+
+double DFT_ComputeXC(XCSolver *s, int ngrid, int nao, unsigned long long d_dm,
+                     unsigned long long d_ao, unsigned long long d_ao_grad,
+                     unsigned long long d_w, unsigned long long d_vxc)
+{
+    return DFT_ComputeXC64(s, ngrid, nao, d_dm, d_ao, d_ao_grad, d_w, d_vxc);
+}
+
+int DFT_ComputeXCAsync(XCSolver *s, long long ngrid, int nao, unsigned long long d_dm,
+                       unsigned long long d_ao, unsigned long long d_ao_grad,
+                       unsigned long long d_w, unsigned long long d_vxc,
+                       unsigned long long d_exc)
+{
+    if (!s) return -1;
+    if (!xc_sweep(s, (long)ngrid, nao, (const double *)d_dm, (const double *)d_ao,
+                  (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc))
+        return -1;
+    if (d_exc && !hip_ok(s, hipMemcpyAsync((void *)d_exc, s->exc.p, sizeof(double), hipMemcpyDeviceToDevice, s->stream), "copy Exc"))
+        return -1;
+    return 0;
+}
+
+void DFT_ComputeCoulomb(XCSolver *s, int nao, unsigned long long d_eri, unsigned long long d_dm,
+                        unsigned long long d_J)
+{
+    if (!s) return;
+    jk(s, nao, (const double *)d_eri, (const double *)d_dm, (double *)d_J, nullptr);
+}
+
+void DFT_ComputeExchange(XCSolver *s, int nao, unsigned long long d_eri, unsigned long long d_dm,
+                         unsigned long long d_K)
+{
+    if (!s) return;
+    jk(s, nao, (const double *)d_eri, (const double *)d_dm, nullptr, (double *)d_K);
+}
+
+void DFT_ComputeJK(XCSolver *s, int nao, unsigned long long d_eri, unsigned long long d_dm,
+                   unsigned long long d_J, unsigned long long d_K)
+{
+    if (!s) return;
+    jk(s, nao, (const double *)d_eri, (const double *)d_dm, (double *)d_J, (double *)d_K);
+}
+
+int DFT_EvalAO(XCSolver *s, long long ngrid, int nao, int nshell, const double *shl_xyz,
+               const int *shl_l, const int *shl_nprim, const int *shl_off, const int *shl_ao,
+               const double *prim_exp, const double *prim_coef, int nprim_total,
+               unsigned long long d_coords, unsigned long long d_ao, unsigned long long d_ao_grad)
+{
+    if (!s) return -1;
+    s->last_error.clear();
+    if (!s->device_ok) { set_error(s, "no usable HIP device"); return -1; }
+    if (ngrid <= 0 || nao <= 0 || nshell <= 0 || nprim_total <= 0) {
+        set_error(s, "bad AO sizes");
+        return -1;
+    }
+    // validate, then pack: [AoShell x nshell][exp x nprim][coef x nprim][AoChunk x nchunk]
+    int next_col = 0;
+    std::vector<AoChunk> chunks;
+    for (int i = 0; i < nshell; ++i) {
+        const int l = shl_l[i], nf = 2 * l + 1;
+        if (l < 0 || l > AO_MAX_L) { set_error(s, "shell %d: l=%d unsupported (max %d)", i, l, AO_MAX_L); return -1; }
+        if (shl_nprim[i] <= 0 || shl_off[i] < 0 || shl_off[i] + shl_nprim[i] > nprim_total) { set_error(s, "shell %d: primitive range out of bounds", i); return -1; }
+        if (shl_ao[i] != next_col) { set_error(s, "shell %d: AO columns must be contiguous and ascending (expected %d, got %d)", i, next_col, shl_ao[i]); return -1; }
+        if (chunks.empty() || chunks.back().ncol + nf > AO_CT)
+            chunks.push_back(AoChunk{i, i, next_col, 0});
+        chunks.back().shell_hi = i + 1;
+        chunks.back().ncol += nf;
+        next_col += nf;
+    }
+    if (next_col != nao) { set_error(s, "shell table covers %d AO columns, nao=%d", next_col, nao); return -1; }
+    const int nchunk = (int)chunks.size();
+    const size_t off_exp = sizeof(AoShell) * nshell;
+    const size_t off_chunk = off_exp + 2 * sizeof(double) * nprim_total;
+    const size_t bytes = off_chunk + sizeof(AoChunk) * nchunk;
+    std::vector<unsigned char> blob(bytes);
+    AoShell *sh = (AoShell *)blob.data();
+    for (int i = 0; i < nshell; ++i) {
+        sh[i].x = shl_xyz[3 * i]; sh[i].y = shl_xyz[3 * i + 1]; sh[i].z = shl_xyz[3 * i + 2];
+        sh[i].l = shl_l[i]; sh[i].nprim = shl_nprim[i]; sh[i].off = shl_off[i]; sh[i].ao = shl_ao[i];
+    }
+    double *pe = (double *)(blob.data() + off_exp);
+    memcpy(pe, prim_exp, sizeof(double) * nprim_total);
+    memcpy(pe + nprim_total, prim_coef, sizeof(double) * nprim_total);
+    memcpy(blob.data() + off_chunk, chunks.data(), sizeof(AoChunk) * nchunk);
+    if (blob != s->shell_blob) {
+        if (!reserve(s, s->shells, bytes, "hipMalloc(shells)")) return -1;
+        if (!hip_ok(s, hipMemcpyAsync(s->shells.p, blob.data(), bytes, hipMemcpyHostToDevice, s->stream), "upload shells") ||
+            !hip_ok(s, hipStreamSynchronize(s->stream), "synchronise"))
+            return -1;
+        s->shell_blob.swap(blob);
+    }
+    const unsigned char *base = (const unsigned char *)s->shells.p;
+    const AoShell *dsh = (const AoShell *)base;
+    const double *dexp = (const double *)(base + off_exp);
+    const double *dcoef = dexp + nprim_total;
+    const AoChunk *dchunks = (const AoChunk *)(base + off_chunk);
+    launch_eval_ao(s->stream, (long)ngrid, nao, nchunk, dsh, dexp, dcoef, dchunks,
+                   (const double *)d_coords, (double *)d_ao, (double *)d_ao_grad);
+    return hip_ok(s, hipGetLastError(), "AO launch") ? 0 : -1;
+}
+
+int DFT_SetOption(XCSolver *s, const char *key, double value)
+{
+    if (!s || !key) return -1;
+    if (!strcmp(key, "quirks")) { s->quirks = value != 0.0; return 0; }
+    if (!strcmp(key, "path")) { s->path = (int)value; return 0; }
+    if (!strcmp(key, "profile")) { s->profile = value != 0.0; return 0; }
+    if (!strcmp(key, "ksplit")) { s->ksplit = value > 0 ? (int)value : 0; return 0; }
+    return -1;
+}
+
+int DFT_SetStream(XCSolver *s, unsigned long long hip_stream)
+{
+    if (!s) return -1;
+    if (s->device_ok) (void)hipStreamSynchronize(s->stream);
+    s->stream = (hipStream_t)hip_stream;
+    return 0;
+}
+
+const char *DFT_GetLastError(XCSolver *s)
+{
+    return s ? s->last_error.c_str() : "";
+}
+
+int DFT_GetTimings(XCSolver *s, double *ms, const char **names, int max_entries)
+{
+    if (!s || !s->device_ok) return 0;
+    (void)hipStreamSynchronize(s->stream);
+    int n = 0;
+    for (size_t i = 0; i < s->n_timed && n < max_entries; ++i, ++n) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, s->timings[i].t0, s->timings[i].t1) != hipSuccess) t = -1.f;
+        if (ms) ms[n] = t;
+        if (names) names[n] = s->timings[i].name;
+    }
+    return n;
+}
+
+} // extern "C"

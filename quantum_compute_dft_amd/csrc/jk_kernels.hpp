@@ -1,0 +1,99 @@
+// Coulomb J and exact-exchange K on the dense ERI, one streaming pass (HBM-bound,
+// 0.25 flop/byte: deliberately NOT reshaped into a GEMM).
+//
+// Replaces
+//   XCSolver::compute_coulomb's cublasDgemv (src/dft_solver.cu:550-555):
+//       J[c] = sum_r eri[r*N2 + c] * dm[r]          (OP_N on the row-major buffer)
+//   the driver's cp.einsum('ijkl,jl->ik', eri4d, dm) (dft.py:218):
+//       K[i][k] = sum_j sum_l eri[(i*n+j)*N2 + k*n+l] * dm[j*n+l]
+//
+// Layout: ERI is (N2, N2) row-major, row r = (i,j), column c = (k,l).
+// A workgroup owns one i, a j-range, and a run of whole k-segments of columns
+// (KB*n <= 1024 columns, 4 per thread, consecutive threads on consecutive
+// columns).  It streams its rows once; per loaded element it does one FMA into
+// the J column partial and one into T[k][l] = sum_j eri * dm[j][l].  At the end
+// T is segment-summed over l through LDS into K[i][k].  Partials are written
+// to slabs and summed in fixed order by the k_*_reduce kernels (deterministic).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace qcdft {
+
+constexpr int JK_COLS = 1024; // columns per workgroup (4 per thread)
+
+template <bool WANT_J, bool WANT_K>
+__global__ __launch_bounds__(256) void k_jk_stream(int n, int KB, int jsplit,
+                                                   const double *__restrict__ eri,
+                                                   const double *__restrict__ dm,
+                                                   double *__restrict__ Jpart,
+                                                   double *__restrict__ Kpart)
+{
+    __shared__ double T[JK_COLS];
+    const size_t N2 = (size_t)n * n;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.y / jsplit, js = blockIdx.y - i * jsplit;
+    const int jper = (n + jsplit - 1) / jsplit;
+    const int jlo = js * jper, jhi = min(n, jlo + jper);
+    const int klo = blockIdx.x * KB, khi = min(n, klo + KB);
+    const int ncol = (khi - klo) * n;       // columns of this block
+    const size_t cbase = (size_t)klo * n;   // first column
+
+    double ja[4] = {0, 0, 0, 0}, ka[4] = {0, 0, 0, 0};
+    int lcol[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = tid + 256 * q;
+        lcol[q] = (c < ncol) ? (c % n) : 0; // l index of column c
+    }
+    for (int j = jlo; j < jhi; ++j) {
+        const size_t r = (size_t)i * n + j;
+        const double *row = eri + r * N2 + cbase;
+        const double dr = WANT_J ? dm[r] : 0.0;
+        const double *drow = dm + (size_t)j * n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = tid + 256 * q;
+            if (c < ncol) {
+                const double e = row[c];
+                if (WANT_J) ja[q] += e * dr;
+                if (WANT_K) ka[q] += e * drow[lcol[q]];
+            }
+        }
+    }
+    if (WANT_J) {
+        double *jp = Jpart + (size_t)blockIdx.y * N2 + cbase;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = tid + 256 * q;
+            if (c < ncol) jp[c] = ja[q];
+        }
+    }
+    if (WANT_K) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = tid + 256 * q;
+            if (c < ncol) T[c] = ka[q];
+        }
+        __syncthreads();
+        if (tid < khi - klo) {
+            double s = 0.0;
+            const double *t = &T[tid * n];
+            for (int l = 0; l < n; ++l) s += t[l];
+            Kpart[((size_t)js * n + i) * n + klo + tid] = s;
+        }
+    }
+}
+
+// out[e] = sum_s part[s*stride + e], fixed order.
+__global__ __launch_bounds__(256) void k_sum_slabs(size_t nelem, int nslab, size_t stride,
+                                                   const double *__restrict__ part,
+                                                   double *__restrict__ out)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nelem) return;
+    double s = 0.0;
+    for (int k = 0; k < nslab; ++k) s += part[(size_t)k * stride + e];
+    out[e] = s;
+}
+
+} // namespace qcdft

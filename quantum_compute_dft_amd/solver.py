@@ -1,0 +1,177 @@
+"""ctypes binding of libdft.so.
+
+`DFTSolverWrapper` mirrors the reference class of the same name
+(dft.py:15-95): same constructor arguments, same `compute_xc` /
+`compute_coulomb` signatures and argument meaning, same error behaviour
+(FileNotFoundError for a missing library, ValueError for an unknown functional,
+RuntimeError when the C side returns a null solver).  Device arrays may be
+torch tensors (`.data_ptr()`), CuPy arrays (`.data.ptr`, what the reference
+passes) or plain integer device addresses.
+
+Extensions beyond the reference class: compute_exchange / compute_jk /
+eval_ao / set_option / timings, all thin calls into the extra C symbols.
+"""
+import ctypes
+import os
+
+from .build import LIB_PATH
+
+_u64 = ctypes.c_uint64
+
+
+def default_library_path():
+    return LIB_PATH
+
+
+def _ptr(a):
+    """Raw device address of a torch tensor / CuPy array / int (0 for None)."""
+    if a is None:
+        return 0
+    if isinstance(a, int):
+        return a
+    if hasattr(a, "data_ptr"):
+        return int(a.data_ptr())
+    data = getattr(a, "data", None)
+    if data is not None and hasattr(data, "ptr"):
+        return int(data.ptr)
+    raise TypeError(f"cannot take a device pointer from {type(a).__name__}")
+
+
+class DFTSolverWrapper:
+    TYPE_LDA = 0
+    TYPE_GGA = 1
+    TYPE_B3LYP = 2
+
+    def __init__(self, lib_path=None, functional_type="lda"):
+        lib_path = lib_path or LIB_PATH
+        if not os.path.exists(lib_path):
+            raise FileNotFoundError(f"Shared library not found at: {lib_path}")
+        self.lib = ctypes.CDLL(os.path.abspath(lib_path))
+        self.functional_type = functional_type.upper()
+        L = self.lib
+        # --- the four reference symbols, declared exactly as dft.py:27-50 does
+        L.DFT_CreateSolver.argtypes = [ctypes.c_int]
+        L.DFT_CreateSolver.restype = ctypes.c_void_p
+        L.DFT_DestroySolver.argtypes = [ctypes.c_void_p]
+        L.DFT_DestroySolver.restype = None
+        L.DFT_ComputeXC.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                    _u64, _u64, _u64, _u64, _u64]
+        L.DFT_ComputeXC.restype = ctypes.c_double
+        L.DFT_ComputeCoulomb.argtypes = [ctypes.c_void_p, ctypes.c_int, _u64, _u64, _u64]
+        L.DFT_ComputeCoulomb.restype = None
+        # --- extensions
+        L.DFT_ComputeXC64.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
+                                      _u64, _u64, _u64, _u64, _u64]
+        L.DFT_ComputeXC64.restype = ctypes.c_double
+        L.DFT_ComputeXCAsync.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
+                                         _u64, _u64, _u64, _u64, _u64, _u64]
+        L.DFT_ComputeXCAsync.restype = ctypes.c_int
+        L.DFT_ComputeExchange.argtypes = [ctypes.c_void_p, ctypes.c_int, _u64, _u64, _u64]
+        L.DFT_ComputeExchange.restype = None
+        L.DFT_ComputeJK.argtypes = [ctypes.c_void_p, ctypes.c_int, _u64, _u64, _u64, _u64]
+        L.DFT_ComputeJK.restype = None
+        dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+        L.DFT_EvalAO.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                                 dp, ip, ip, ip, ip, dp, dp, ctypes.c_int, _u64, _u64, _u64]
+        L.DFT_EvalAO.restype = ctypes.c_int
+        L.DFT_SetOption.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]
+        L.DFT_SetOption.restype = ctypes.c_int
+        L.DFT_SetStream.argtypes = [ctypes.c_void_p, _u64]
+        L.DFT_SetStream.restype = ctypes.c_int
+        L.DFT_GetLastError.argtypes = [ctypes.c_void_p]
+        L.DFT_GetLastError.restype = ctypes.c_char_p
+        L.DFT_GetTimings.argtypes = [ctypes.c_void_p, dp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
+        L.DFT_GetTimings.restype = ctypes.c_int
+        L.DFT_GetVersion.argtypes = []
+        L.DFT_GetVersion.restype = ctypes.c_int
+
+        if self.functional_type == "LDA":
+            c_type = self.TYPE_LDA
+        elif self.functional_type == "GGA":
+            c_type = self.TYPE_GGA
+        elif self.functional_type == "B3LYP":
+            c_type = self.TYPE_B3LYP
+        else:
+            raise ValueError(f"Unsupported functional type: {self.functional_type}")
+
+        self.solver = L.DFT_CreateSolver(c_type)
+        if not self.solver:
+            raise RuntimeError("Failed to create C++ DFT Solver instance.")
+
+    def __del__(self):
+        if hasattr(self, "lib") and hasattr(self, "solver") and self.solver:
+            self.lib.DFT_DestroySolver(self.solver)
+            self.solver = None
+
+    # ---- reference surface (dft.py:69-95) -------------------------------
+    def compute_xc(self, ngrid, nao, d_dm, d_ao, d_weights, d_vxc, d_ao_grad=None):
+        energy = self.lib.DFT_ComputeXC64(
+            self.solver, int(ngrid), int(nao),
+            _u64(_ptr(d_dm)), _u64(_ptr(d_ao)), _u64(_ptr(d_ao_grad)),
+            _u64(_ptr(d_weights)), _u64(_ptr(d_vxc)))
+        self._check()
+        return energy
+
+    def compute_coulomb(self, nao, d_eri, d_dm, d_J):
+        self.lib.DFT_ComputeCoulomb(self.solver, int(nao), _u64(_ptr(d_eri)),
+                                    _u64(_ptr(d_dm)), _u64(_ptr(d_J)))
+        self._check()
+
+    # ---- extensions -------------------------------------------------------
+    def compute_xc_async(self, ngrid, nao, d_dm, d_ao, d_weights, d_vxc, d_exc, d_ao_grad=None):
+        rc = self.lib.DFT_ComputeXCAsync(
+            self.solver, int(ngrid), int(nao), _u64(_ptr(d_dm)), _u64(_ptr(d_ao)),
+            _u64(_ptr(d_ao_grad)), _u64(_ptr(d_weights)), _u64(_ptr(d_vxc)), _u64(_ptr(d_exc)))
+        self._check()
+        return rc
+
+    def compute_exchange(self, nao, d_eri, d_dm, d_K):
+        self.lib.DFT_ComputeExchange(self.solver, int(nao), _u64(_ptr(d_eri)),
+                                     _u64(_ptr(d_dm)), _u64(_ptr(d_K)))
+        self._check()
+
+    def compute_jk(self, nao, d_eri, d_dm, d_J, d_K):
+        self.lib.DFT_ComputeJK(self.solver, int(nao), _u64(_ptr(d_eri)), _u64(_ptr(d_dm)),
+                               _u64(_ptr(d_J)), _u64(_ptr(d_K)))
+        self._check()
+
+    def eval_ao(self, shells, d_coords, ngrid, d_ao, d_ao_grad=None):
+        """shells: a basis.ShellTable (host numpy arrays, see basis.py)."""
+        import numpy as np
+        dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+        xyz = np.ascontiguousarray(shells.xyz, dtype=np.float64)
+        ls = np.ascontiguousarray(shells.l, dtype=np.int32)
+        npr = np.ascontiguousarray(shells.nprim, dtype=np.int32)
+        off = np.ascontiguousarray(shells.off, dtype=np.int32)
+        aoc = np.ascontiguousarray(shells.ao, dtype=np.int32)
+        ex = np.ascontiguousarray(shells.exp, dtype=np.float64)
+        cf = np.ascontiguousarray(shells.coef, dtype=np.float64)
+        rc = self.lib.DFT_EvalAO(
+            self.solver, int(ngrid), int(shells.nao), int(len(ls)),
+            xyz.ctypes.data_as(dp), ls.ctypes.data_as(ip), npr.ctypes.data_as(ip),
+            off.ctypes.data_as(ip), aoc.ctypes.data_as(ip), ex.ctypes.data_as(dp),
+            cf.ctypes.data_as(dp), int(len(ex)), _u64(_ptr(d_coords)), _u64(_ptr(d_ao)),
+            _u64(_ptr(d_ao_grad)))
+        self._check()
+        return rc
+
+    def set_option(self, key, value):
+        if self.lib.DFT_SetOption(self.solver, key.encode(), float(value)) != 0:
+            raise KeyError(key)
+
+    def set_stream(self, hip_stream):
+        self.lib.DFT_SetStream(self.solver, _u64(int(hip_stream)))
+
+    def last_error(self):
+        return (self.lib.DFT_GetLastError(self.solver) or b"").decode()
+
+    def timings(self, max_entries=16):
+        ms = (ctypes.c_double * max_entries)()
+        names = (ctypes.c_char_p * max_entries)()
+        n = self.lib.DFT_GetTimings(self.solver, ms, names, max_entries)
+        return [(names[i].decode(), ms[i]) for i in range(n)]
+
+    def _check(self):
+        err = self.lib.DFT_GetLastError(self.solver)
+        if err:
+            raise RuntimeError("libdft: " + err.decode())

@@ -1,0 +1,85 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and
+exports every symbol include/dft_solver.h declares; the Python mirror of
+DFTSolverWrapper keeps the reference's error behaviour (dft.py:15-67).  No
+compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import quantum_compute_dft_amd as q
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    return q.build_library()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dft_solver.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(DFT_[A-Za-z0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_four_reference_symbols():
+    names = _declared_symbols()
+    for ref in ("DFT_CreateSolver", "DFT_DestroySolver", "DFT_ComputeXC", "DFT_ComputeCoulomb"):
+        assert ref in names
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    lib = ctypes.CDLL(libpath)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in include/dft_solver.h but not exported"
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "dft_solver.h"\nint main(void){return SOLVER_B3LYP==2?0:1;}\n')
+    import subprocess
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    "-c", str(src), "-o", str(tmp_path / "t.o")], check=True)
+
+
+def test_wrapper_error_behaviour(libpath):
+    with pytest.raises(FileNotFoundError):
+        q.DFTSolverWrapper("/nonexistent/dft.so", "LDA")
+    with pytest.raises(ValueError):
+        q.DFTSolverWrapper(libpath, "MP2")
+    w = q.DFTSolverWrapper(libpath, "b3lyp")  # case-insensitive like the reference
+    assert w.functional_type == "B3LYP" and w.solver
+
+
+def test_bad_solver_type_returns_null_and_null_solver_is_inert(libpath):
+    lib = ctypes.CDLL(libpath)
+    lib.DFT_CreateSolver.restype = ctypes.c_void_p
+    lib.DFT_CreateSolver.argtypes = [ctypes.c_int]
+    assert not lib.DFT_CreateSolver(7)          # dft_solver.cu:681
+    lib.DFT_ComputeXC.restype = ctypes.c_double
+    lib.DFT_ComputeXC.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_uint64] * 5
+    assert lib.DFT_ComputeXC(None, 10, 2, 0, 0, 0, 0, 0) == 0.0   # dft_solver.cu:695
+    lib.DFT_ComputeCoulomb.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_uint64] * 3
+    lib.DFT_ComputeCoulomb(None, 2, 0, 0, 0)     # dft_solver.cu:711: no-op
+    lib.DFT_DestroySolver.argtypes = [ctypes.c_void_p]
+    lib.DFT_DestroySolver(None)                  # dft_solver.cu:685
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "quantum_compute_dft_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
+
+
+def test_no_gpu_means_loud_failure(libpath):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    w = q.DFTSolverWrapper(libpath, "LDA")
+    with pytest.raises(RuntimeError):
+        w.compute_xc(8, 2, 0, 0, 0, 0)
