@@ -8,7 +8,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdft.so")
 SOURCES = ["dft_api.hip"]
-HEADERS = ["xc_functionals.hpp", "xc_kernels.hpp", "jk_kernels.hpp", "ao_kernels.hpp",
+HEADERS = ["xc_functionals.hpp", "xc_kernels.hpp", "xc_fast_kernels.hpp", "jk_kernels.hpp", "ao_kernels.hpp",
            os.path.join("..", "..", "include", "dft_solver.h")]
 
 
@@ -25,8 +25,11 @@ def build_library(force=False, verbose=False):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(LIB_DIR, exist_ok=True)
+    # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950's register file is unified);
+    # without it hipcc 7.2 can wrap every MFMA group of a loop in v_accvgpr_write/read copy storms
+    # (measured on the fp64 probe: 35 -> 75 TFLOP/s, profiles/r01_mfma_f64_probe2.txt).
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function"]
+           "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wall", "-Wno-unused-function"]
     cmd += [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

@@ -10,7 +10,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <limits>
 #include <string>
 #include <vector>
@@ -18,6 +20,7 @@
 #include "../../include/dft_solver.h"
 #include "ao_kernels.hpp"
 #include "jk_kernels.hpp"
+#include "xc_fast_kernels.hpp"
 #include "xc_kernels.hpp"
 
 using namespace qcdft;
@@ -43,7 +46,7 @@ struct XCSolver {
     int num_cu = 256;
     // options
     int quirks = 1;
-    int path = 0; // 0 MFMA, 1 VALU validation kernels
+    int path = 0; // 0 auto (persistent MFMA kernels when nao <= 128), 1 VALU validation, 2 generic MFMA
     int profile = 0;
     int ksplit = 0;
     // workspace
@@ -125,6 +128,18 @@ int auto_ksplit(const XCSolver *s, long ngrid, int nblk)
     return (int)want;
 }
 
+#define QCDFT_NT_SWITCH(NTV, CALL)              \
+    switch (NTV) {                               \
+    case 1: { constexpr int NT = 1; CALL; } break; \
+    case 2: { constexpr int NT = 2; CALL; } break; \
+    case 3: { constexpr int NT = 3; CALL; } break; \
+    case 4: { constexpr int NT = 4; CALL; } break; \
+    case 5: { constexpr int NT = 5; CALL; } break; \
+    case 6: { constexpr int NT = 6; CALL; } break; \
+    case 7: { constexpr int NT = 7; CALL; } break; \
+    default: { constexpr int NT = 8; CALL; } break; \
+    }
+
 // The sweep: everything on s->stream, Exc left in s->exc (device).
 bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *ao,
               const double *ao_grad, const double *w, double *vxc)
@@ -146,10 +161,19 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     }
     const int NP = ((nao + 15) / 16) * 16;
     const int nblk = (nao + 127) / 128;
-    const int nsplit = auto_ksplit(s, ngrid, nblk * nblk);
-    long chunk = (ngrid + nsplit - 1) / nsplit;
-    chunk = ((chunk + 31) / 32) * 32;
-    const int nslab = (int)((ngrid + chunk - 1) / chunk);
+    const bool fast = s->path == 0 && nao <= 128;
+    const int ntv = NP / 16;
+    int nslab;
+    long chunk = 0;
+    if (fast) {
+        const long ntile = (ngrid + FK_ROWS - 1) / FK_ROWS;
+        nslab = (int)std::min<long>(s->num_cu, ntile); // one persistent workgroup per CU
+    } else {
+        const int nsplit = auto_ksplit(s, ngrid, nblk * nblk);
+        chunk = (ngrid + nsplit - 1) / nsplit;
+        chunk = ((chunk + 31) / 32) * 32;
+        nslab = (int)((ngrid + chunk - 1) / chunk);
+    }
     const long nxb = (ngrid + 255) / 256;
     const size_t ng = (size_t)ngrid;
 
@@ -179,7 +203,12 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     }
     {
         ScopedTimer t(s, "rho");
-        if (s->path == 0) {
+        const int vec16 = (nao % 2 == 0) && ((((uintptr_t)ao | (uintptr_t)gx | (uintptr_t)gy | (uintptr_t)gz) & 15) == 0);
+        if (fast) {
+            dim3 g((unsigned)nslab);
+            if (gga) { QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_rho_fast<NT, true>), g, dim3(FK_THREADS), 0, st, ngrid, nao, vec16, ao, gx, gy, gz, Dp, rho, grad, sigma)) }
+            else     { QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_rho_fast<NT, false>), g, dim3(FK_THREADS), 0, st, ngrid, nao, vec16, ao, gx, gy, gz, Dp, rho, grad, sigma)) }
+        } else if (s->path != 1) {
             dim3 g((unsigned)((ngrid + 63) / 64));
             if (gga) hipLaunchKernelGGL(k_rho_mfma<true>, g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
             else     hipLaunchKernelGGL(k_rho_mfma<false>, g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
@@ -199,7 +228,12 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     }
     {
         ScopedTimer t(s, "vxc");
-        if (s->path == 0) {
+        const int vec16 = (nao % 2 == 0) && ((((uintptr_t)ao | (uintptr_t)gx | (uintptr_t)gy | (uintptr_t)gz) & 15) == 0);
+        if (fast) {
+            dim3 g((unsigned)nslab);
+            if (gga) { QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_vxc_fast<NT, true>), g, dim3(FK_THREADS), 0, st, ngrid, nao, vec16, ao, gx, gy, gz, coef, slabs)) }
+            else     { QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_vxc_fast<NT, false>), g, dim3(FK_THREADS), 0, st, ngrid, nao, vec16, ao, gx, gy, gz, coef, slabs)) }
+        } else if (s->path != 1) {
             dim3 g((unsigned)nslab, nblk, nblk);
             if (gga) hipLaunchKernelGGL(k_vxc_mfma<true>, g, dim3(256), 0, st, ngrid, nao, chunk, ao, gx, gy, gz, coef, slabs);
             else     hipLaunchKernelGGL(k_vxc_mfma<false>, g, dim3(256), 0, st, ngrid, nao, chunk, ao, gx, gy, gz, coef, slabs);
@@ -211,9 +245,9 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     }
     {
         ScopedTimer t(s, "reduce_vxc");
-        dim3 g((unsigned)(((size_t)nao * nao + 255) / 256));
-        if (s->type == SOLVER_B3LYP) hipLaunchKernelGGL(k_reduce_slabs<true>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
-        else                         hipLaunchKernelGGL(k_reduce_slabs<false>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
+        dim3 g((unsigned)(((size_t)nao * nao + 63) / 64));
+        if (s->type == SOLVER_B3LYP) hipLaunchKernelGGL(k_reduce_slabs4<true>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
+        else                         hipLaunchKernelGGL(k_reduce_slabs4<false>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
     }
     return hip_ok(s, hipGetLastError(), "XC sweep launch");
 }

@@ -91,12 +91,29 @@ def test_sweep_matches_oracle(dev, xc_type, ngrid, nao):
     _check(exc, v, exc_ref, v_ref)
 
 
+@pytest.mark.parametrize("path", [1, 2])   # 1 = plain-VALU validation kernels, 2 = generic MFMA kernels
 @pytest.mark.parametrize("xc_type", [0, 1, 2])
-def test_valu_validation_path_matches_oracle(dev, xc_type):
-    dm, ao, gr, w = synth_inputs(777, 37, seed=5)
-    exc_ref, v_ref = oracle.compute_xc(xc_type, dm, ao, w, gr)
-    exc, v = _run(_solver(xc_type, path=1), dm, ao, gr if xc_type else None, w, dev)
-    _check(exc, v, exc_ref, v_ref)
+def test_alternative_kernel_paths_match_oracle(dev, xc_type, path):
+    for ngrid, nao in ((777, 37), (1500, 114)):
+        dm, ao, gr, w = synth_inputs(ngrid, nao, seed=5)
+        exc_ref, v_ref = oracle.compute_xc(xc_type, dm, ao, w, gr)
+        exc, v = _run(_solver(xc_type, path=path), dm, ao, gr if xc_type else None, w, dev)
+        _check(exc, v, exc_ref, v_ref)
+
+
+def test_unaligned_base_pointers(dev):
+    # a view that starts 8 bytes into an allocation: the 16-byte load form must not be used
+    ngrid, nao = 1000, 30
+    dm, ao, gr, w = synth_inputs(ngrid, nao, seed=31)
+    exc_ref, v_ref = oracle.compute_xc(1, dm, ao, w, gr)
+    sv = _solver(1)
+    pad = lambda a: torch.cat([torch.zeros(1, dtype=torch.float64, device=dev),
+                               torch.as_tensor(a, device=dev).reshape(-1)])[1:]
+    d_ao, d_gr = pad(ao), pad(gr)
+    assert d_ao.data_ptr() % 16 == 8
+    d_v = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
+    exc = sv.compute_xc(ngrid, nao, torch.as_tensor(dm, device=dev), d_ao, torch.as_tensor(w, device=dev), d_v, d_gr)
+    _check(exc, d_v.cpu().numpy(), exc_ref, v_ref)
 
 
 @pytest.mark.parametrize("xc_type", [0, 1])
