@@ -20,7 +20,7 @@
 #include "../../include/dft_solver.h"
 #include "ao_kernels.hpp"
 #include "jk_kernels.hpp"
-#include "xc_fast_kernels.hpp"
+#include "xc_ws_kernels.hpp"
 #include "xc_kernels.hpp"
 
 using namespace qcdft;
@@ -46,7 +46,7 @@ struct XCSolver {
     int num_cu = 256;
     // options
     int quirks = 1;
-    int path = 0; // 0 auto (persistent MFMA kernels when nao <= 128), 1 VALU validation, 2 generic MFMA
+    int path = 0; // 0 auto (wave-specialised persistent kernels when nao <= 128), 1 VALU validation, 2 generic MFMA
     int profile = 0;
     int ksplit = 0;
     // workspace
@@ -166,8 +166,8 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     int nslab;
     long chunk = 0;
     if (fast) {
-        const long ntile = (ngrid + FK_ROWS - 1) / FK_ROWS;
-        nslab = (int)std::min<long>(s->num_cu, ntile); // one persistent workgroup per CU
+        const long ntile = (ngrid + WS_ROWS - 1) / WS_ROWS;
+        nslab = (int)std::min<long>(s->num_cu, ntile); // one persistent, wave-specialised workgroup per CU
     } else {
         const int nsplit = auto_ksplit(s, ngrid, nblk * nblk);
         chunk = (ngrid + nsplit - 1) / nsplit;
@@ -206,8 +206,10 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
         const int vec16 = (nao % 2 == 0) && ((((uintptr_t)ao | (uintptr_t)gx | (uintptr_t)gy | (uintptr_t)gz) & 15) == 0);
         if (fast) {
             dim3 g((unsigned)nslab);
-            if (gga) { QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_rho_fast<NT, true>), g, dim3(FK_THREADS), 0, st, ngrid, nao, vec16, ao, gx, gy, gz, Dp, rho, grad, sigma)) }
-            else     { QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_rho_fast<NT, false>), g, dim3(FK_THREADS), 0, st, ngrid, nao, vec16, ao, gx, gy, gz, Dp, rho, grad, sigma)) }
+#define QCDFT_RHO(G, V) QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_rho_ws<NT, G, V>), g, dim3(WS_THREADS), 0, st, ngrid, nao, ao, gx, gy, gz, Dp, rho, grad, sigma))
+            if (gga) { if (vec16) { QCDFT_RHO(true, true) } else { QCDFT_RHO(true, false) } }
+            else     { if (vec16) { QCDFT_RHO(false, true) } else { QCDFT_RHO(false, false) } }
+#undef QCDFT_RHO
         } else if (s->path != 1) {
             dim3 g((unsigned)((ngrid + 63) / 64));
             if (gga) hipLaunchKernelGGL(k_rho_mfma<true>, g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
@@ -231,8 +233,10 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
         const int vec16 = (nao % 2 == 0) && ((((uintptr_t)ao | (uintptr_t)gx | (uintptr_t)gy | (uintptr_t)gz) & 15) == 0);
         if (fast) {
             dim3 g((unsigned)nslab);
-            if (gga) { QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_vxc_fast<NT, true>), g, dim3(FK_THREADS), 0, st, ngrid, nao, vec16, ao, gx, gy, gz, coef, slabs)) }
-            else     { QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_vxc_fast<NT, false>), g, dim3(FK_THREADS), 0, st, ngrid, nao, vec16, ao, gx, gy, gz, coef, slabs)) }
+#define QCDFT_VXC(G, V) QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_vxc_ws<NT, G, V>), g, dim3(WS_THREADS), 0, st, ngrid, nao, ao, gx, gy, gz, coef, slabs))
+            if (gga) { if (vec16) { QCDFT_VXC(true, true) } else { QCDFT_VXC(true, false) } }
+            else     { if (vec16) { QCDFT_VXC(false, true) } else { QCDFT_VXC(false, false) } }
+#undef QCDFT_VXC
         } else if (s->path != 1) {
             dim3 g((unsigned)nslab, nblk, nblk);
             if (gga) hipLaunchKernelGGL(k_vxc_mfma<true>, g, dim3(256), 0, st, ngrid, nao, chunk, ao, gx, gy, gz, coef, slabs);

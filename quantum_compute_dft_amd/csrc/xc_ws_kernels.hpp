@@ -1,0 +1,482 @@
+// Wave-specialised contraction kernels for nao <= 128 (NT = ceil(nao/16) <= 8 MFMA column
+// tiles): the sizes of every BASELINE config that fits dense ERIs (H2O/def2-SVP 24,
+// Benzene/def2-SVP 114, sto-3g 7..80).  Same mathematics as xc_kernels.hpp (the generic
+// path for nao > 128).
+//
+// Why this shape (measured on MI355X, profiles/r01_*): a lock-stepped workgroup alternates
+// "HBM loads in flight" and "MFMA / epilogue", so neither pipe is busy more than ~60 % of
+// the time (rho 124 us, vxc 129 us against an 83 us HBM floor for 4 AO planes).  Here one
+// 512-thread workgroup per CU is split by role:
+//   waves 0-3  MFMA waves   : fp64 MFMA only, operands from an LDS ring;
+//   waves 4-7  loader waves : 16-byte coalesced plane loads (16 lanes = 256 contiguous bytes
+//                             of one grid row; thread = (row, seg), columns 32j+2seg+{0,1}),
+//                             two 16-point sub-tiles always in flight in registers, LDS
+//                             staging, and the cheap VALU work (B rows / row dots).
+// The roles meet at ONE s_barrier per sub-tile; the ring is deep enough that a stage is
+// rewritten only after a later barrier than its last read, so no flags are needed:
+//   vxc : loaders write stage i (sub-tile i) at step i, MFMA waves read it at step i+2.
+//   rho : loaders write AO stage i at step i, MFMA waves form X(i) at step i+1 into an
+//         X ring, loaders take the row dots of sub-tile i at step i+2.
+// Persistent: workgroup b owns sub-tiles b, b+grid, ... (neighbouring CUs stream
+// neighbouring HBM pages).  LDS leading dimensions: AO tile = 2 or 18 (mod 32) doubles (the
+// 16-row x 2-k A-operand read hits 32 distinct bank pairs), X/P/Q tiles = 16 (mod 32)
+// (2 k-rows x 16 columns likewise).
+//
+// References replaced: src/dft_solver.cu:294-307,346-380 (rho kernels),
+// :309-513 pass-2 B rows + :541-548 cublasDgemm (Vxc).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "xc_kernels.hpp"
+
+namespace qcdft {
+
+#ifdef QCDFT_STAMPS // diagnostic build only (tools/ws_stamp_probe.hip): per-wave cycle shares
+__device__ unsigned long long g_stamps[256 * 8 * 4];
+#define QCDFT_T(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#define QCDFT_ACC(slot, a, b) st_acc[slot] += (b) - (a)
+#else
+#define QCDFT_T(var)
+#define QCDFT_ACC(slot, a, b)
+#endif
+
+constexpr int WS_ROWS = 16;      // grid points per sub-tile
+constexpr int WS_THREADS = 512;  // 4 MFMA waves + 4 loader waves
+constexpr int WS_RING = 4;       // LDS ring depth (static stage index under 4x unrolling)
+
+template <int NT> struct WsCfg {
+    static constexpr int NCOL = 16 * NT;                      // padded AO columns
+    static constexpr int JN = (NT + 1) / 2;                   // 32-column groups per row
+    static constexpr int LDA = NCOL + 2;                      // = 2 or 18 (mod 32)
+    static constexpr int LDX = ((NCOL + 31) / 32) * 32 + 16;  // = 16 (mod 32)
+};
+
+// Plane tiles are read with BUFFER loads: a wave-uniform descriptor (SGPRs) whose base is the
+// tile's first row and whose range ends at the END OF THE PLANE, plus one 32-bit per-thread byte
+// offset and immediate column offsets.  The hardware range check returns zeros for rows past
+// the grid, so the loader stream carries no masks, clamps or 64-bit VALU address arithmetic --
+// it has to fit in the ~2.5 VALU issue slots per fp64 MFMA that a wave gets next to a
+// saturating MFMA wave on the same SIMD (measured, tools/coissue_probe.hip).
+// Columns >= nao of a staged row hold finite data of the next row; they only ever multiply
+// exact zeros (zero-padded Ds rows / discarded V tiles).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_tile_rsrc(const double *plane, long plane_elems,
+                                                                  long first_elem)
+{
+    const long remain = (plane_elems - first_elem) * 8; // bytes to the end of the plane (> 0)
+    const unsigned nrec = remain > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)remain;
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(plane + first_elem), 0, nrec, 0x00020000);
+}
+// pair (c, c+1) of one row: `voff` = byte offset of (row, 2*seg) in the tile, IMM = 256*j
+template <bool VEC, int IMM>
+__device__ __forceinline__ void buf_load_pair(__amdgpu_buffer_rsrc_t r, unsigned voff, double &a, double &b)
+{
+    if (VEC) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM, 0, 0);
+        a = __hiloint2double((int)v[1], (int)v[0]);
+        b = __hiloint2double((int)v[3], (int)v[2]);
+    } else { // odd nao or 8-byte aligned base: two 8-byte loads
+        const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM, 0, 0);
+        const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM + 8, 0, 0);
+        a = __hiloint2double((int)lo[1], (int)lo[0]);
+        b = __hiloint2double((int)hi[1], (int)hi[0]);
+    }
+}
+template <int JN, bool VEC, int J = 0>
+__device__ __forceinline__ void buf_load_row(__amdgpu_buffer_rsrc_t r, unsigned voff, double (&dst)[2 * JN])
+{
+    if constexpr (J < JN) {
+        buf_load_pair<VEC, 256 * J>(r, voff, dst[2 * J], dst[2 * J + 1]);
+        buf_load_row<JN, VEC, J + 1>(r, voff, dst);
+    }
+}
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+    return __hiloint2double((int)v[1], (int)v[0]);
+}
+
+// Sum over the 16 lanes of a DPP row with row rotations: pure VALU, no LDS traffic (the
+// ds_bpermute butterfly cost 21 us of a 147 us kernel).  Every lane ends with the total.
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v)
+{
+    v += dpp_mov_f64<0x128>(v); // row_ror:8
+    v += dpp_mov_f64<0x124>(v); // row_ror:4
+    v += dpp_mov_f64<0x122>(v); // row_ror:2
+    v += dpp_mov_f64<0x121>(v); // row_ror:1
+    return v;
+}
+
+// ------------------------------------------------------------------ Vxc ----
+// V[a][b] += sum_g Q[g][a] P[g][b],  Q = sum_c coef_c * plane_c,  P = AO.
+template <int NT, bool GRAD, bool VEC>
+__global__ __launch_bounds__(WS_THREADS, 2) void k_vxc_ws(long ngrid, int nao,
+                                                          const double *__restrict__ ao,
+                                                          const double *__restrict__ gx,
+                                                          const double *__restrict__ gy,
+                                                          const double *__restrict__ gz,
+                                                          const double *__restrict__ coef,
+                                                          double *__restrict__ slabs)
+{
+    using C = WsCfg<NT>;
+    constexpr int TILE = WS_ROWS * C::LDX;
+    constexpr int NTW = (NT + 1) / 2; // MFMA tiles per wave along each of a, b
+    __shared__ double Ps[WS_RING * TILE];
+    __shared__ double Qs[WS_RING * TILE];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long ntile = (ngrid + WS_ROWS - 1) / WS_ROWS;
+    // sub-tiles of this workgroup: blockIdx.x + k*gridDim.x, k < nloc
+    const long nloc = (ntile > (long)blockIdx.x) ? (ntile - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const long nstep = nloc + 2; // ring latency of two steps
+
+    if (wave < 4) {
+        // ---------------------------------------------------------- MFMA role
+        const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+        const int wa = wave >> 1, wb = wave & 1;
+        const int na = (NT - wa + 1) / 2, nb = (NT - wb + 1) / 2; // owned tiles wa+2i, wb+2j
+        d4 acc[NTW][NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+#ifdef QCDFT_STAMPS
+        unsigned long long st_acc[4] = {0, 0, 0, 0};
+#endif
+        for (long base = 0; base < nstep; base += WS_RING) {
+#pragma unroll
+            for (int u = 0; u < WS_RING; ++u) {
+                const long step = base + u;
+                QCDFT_T(ta);
+#if defined(QCDFT_EXP) && QCDFT_EXP == 1
+                if (false) {
+#else
+                if (step >= 2 && step < nstep) { // consume sub-tile step-2 from stage (u+2)%4
+#endif
+                    const double *P = Ps + ((u + 2) % WS_RING) * TILE;
+                    const double *Q = Qs + ((u + 2) % WS_RING) * TILE;
+#pragma unroll
+                    for (int ks = 0; ks < WS_ROWS / 4; ++ks) {
+                        const int o = (4 * ks + lk) * C::LDX + li;
+                        double af[NTW], bf[NTW];
+#pragma unroll
+                        for (int i = 0; i < NTW; ++i) {
+                            af[i] = Q[o + 16 * min(wa + 2 * i, NT - 1)]; // clamped: unowned tiles skipped below
+                            bf[i] = P[o + 16 * min(wb + 2 * i, NT - 1)];
+                        }
+#pragma unroll
+                        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                            for (int j = 0; j < NTW; ++j)
+                                if ((2 * i + 1 < NT || i < na) && (2 * j + 1 < NT || j < nb))
+                                    acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+                    }
+                }
+                QCDFT_T(tb);
+                __syncthreads();
+                QCDFT_T(tc);
+                QCDFT_ACC(0, ta, tb);
+                QCDFT_ACC(1, tb, tc);
+            }
+        }
+#ifdef QCDFT_STAMPS
+        if ((tid & 63) == 0) { g_stamps[(blockIdx.x * 8 + wave) * 4 + 0] = st_acc[0]; g_stamps[(blockIdx.x * 8 + wave) * 4 + 1] = st_acc[1]; }
+#endif
+        double *slab = slabs + (size_t)blockIdx.x * nao * nao;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                if (i >= na || j >= nb) continue;
+                const int b = 16 * (wb + 2 * j) + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int a = 16 * (wa + 2 * i) + lk + 4 * r;
+                    if (a < nao && b < nao) slab[(size_t)a * nao + b] = acc[i][j][r];
+                }
+            }
+    } else {
+        // -------------------------------------------------------- loader role
+        // The loader stream is short (~200 instructions per step) but latency-critical; at equal
+        // priority the SIMD's arbiter (oldest first) lets the back-to-back MFMA wave starve it
+        // (measured with s_memtime stamps: 7k cycles per step).  The MFMA wave needs one issue
+        // slot per 64 cycles, so giving the loaders priority costs it nothing.
+        __builtin_amdgcn_s_setprio(3);
+        const int lt = tid - 256, row = lt >> 4, seg = lt & 15;
+        const double *c0 = coef, *c1 = coef + (size_t)ngrid, *c2 = coef + 2 * (size_t)ngrid,
+                     *c3 = coef + 3 * (size_t)ngrid;
+        // two register sets: sub-tiles s and s+1 in flight
+        double p0[2][2 * C::JN], p1[2][2 * C::JN], p2[2][2 * C::JN], p3[2][2 * C::JN];
+        double k0[2], k1[2], k2[2], k3[2];
+
+        // Loads are issued UNCONDITIONALLY (sub-tile index clamped to the workgroup's last one):
+        // with a conditional issue the number of outstanding loads is path-dependent and the
+        // compiler falls back to `s_waitcnt vmcnt(0)`, which drains the younger register set as
+        // well and collapses the prefetch to one step (measured: 7k cycles per step).
+        const long plane = ngrid * (long)nao;
+        const unsigned voff = (unsigned)(row * nao + 2 * seg) * 8u, koff = (unsigned)row * 8u;
+        auto issue = [&](int set, long s) {
+            const long row0 = (blockIdx.x + min(s, nloc - 1) * gridDim.x) * WS_ROWS; // wave-uniform
+            const long e0 = row0 * nao;
+            k0[set] = buf_load_f64(plane_tile_rsrc(c0, ngrid, row0), koff);
+            if (GRAD) {
+                k1[set] = buf_load_f64(plane_tile_rsrc(c1, ngrid, row0), koff);
+                k2[set] = buf_load_f64(plane_tile_rsrc(c2, ngrid, row0), koff);
+                k3[set] = buf_load_f64(plane_tile_rsrc(c3, ngrid, row0), koff);
+            }
+            buf_load_row<C::JN, VEC>(plane_tile_rsrc(ao, plane, e0), voff, p0[set]);
+            if (GRAD) {
+                buf_load_row<C::JN, VEC>(plane_tile_rsrc(gx, plane, e0), voff, p1[set]);
+                buf_load_row<C::JN, VEC>(plane_tile_rsrc(gy, plane, e0), voff, p2[set]);
+                buf_load_row<C::JN, VEC>(plane_tile_rsrc(gz, plane, e0), voff, p3[set]);
+            }
+        };
+        issue(0, 0);
+        issue(1, 1);
+#ifdef QCDFT_STAMPS
+        unsigned long long st_acc[4] = {0, 0, 0, 0};
+#endif
+
+        for (long base = 0; base < nstep; base += WS_RING) {
+#pragma unroll
+            for (int u = 0; u < WS_RING; ++u) {
+                const long step = base + u;
+                const int set = u & 1;
+                QCDFT_T(ta);
+#ifdef QCDFT_STAMPS
+                asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); // the 20 loads of the newer set may stay in flight
+#endif
+                QCDFT_T(tw);
+#if defined(QCDFT_EXP) && QCDFT_EXP == 2
+                if (step < 2)
+#endif
+                { // stage sub-tile `step` into ring slot u (steps >= nloc stage rows that are never read;
+                  // rows past the grid arrive as zeros from the range-checked loads)
+                    double *P = Ps + u * TILE, *Q = Qs + u * TILE;
+#pragma unroll
+                    for (int j = 0; j < C::JN; ++j) {
+                        const int c = 32 * j + 2 * seg;
+                        if (c < C::NCOL) {
+                            const double a0 = p0[set][2 * j], b0 = p0[set][2 * j + 1];
+                            double qa = k0[set] * a0, qb = k0[set] * b0;
+                            if (GRAD) {
+                                qa += k1[set] * p1[set][2 * j] + k2[set] * p2[set][2 * j] + k3[set] * p3[set][2 * j];
+                                qb += k1[set] * p1[set][2 * j + 1] + k2[set] * p2[set][2 * j + 1] + k3[set] * p3[set][2 * j + 1];
+                            }
+                            *reinterpret_cast<double2 *>(&Q[row * C::LDX + c]) = make_double2(qa, qb);
+                            *reinterpret_cast<double2 *>(&P[row * C::LDX + c]) = make_double2(a0, b0);
+                        }
+                    }
+                    QCDFT_T(tm);
+                    issue(set, step + 2);
+                    QCDFT_ACC(3, tw, tm);
+                }
+                QCDFT_T(tb);
+                __syncthreads();
+                QCDFT_T(tc);
+                QCDFT_ACC(0, ta, tw);
+                QCDFT_ACC(1, tw, tb);
+                QCDFT_ACC(2, tb, tc);
+            }
+        }
+#ifdef QCDFT_STAMPS
+        if ((tid & 63) == 0) { for (int q = 0; q < 4; ++q) g_stamps[(blockIdx.x * 8 + wave) * 4 + q] = st_acc[q]; }
+#endif
+    }
+}
+
+// ------------------------------------------------------------------ rho ----
+// rho_g = sum_v X[g][v] AO[g][v],  grad rho_g = 2 sum_v X[g][v] dAO[g][v],  X = AO . Ds.
+// MFMA wave w owns column tiles {w, w+4}: their slices of Ds stay in registers.
+template <int NT, bool GRAD, bool VEC>
+__global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
+                                                          const double *__restrict__ ao,
+                                                          const double *__restrict__ gx,
+                                                          const double *__restrict__ gy,
+                                                          const double *__restrict__ gz,
+                                                          const double *__restrict__ Dp,
+                                                          double *__restrict__ rho,
+                                                          double *__restrict__ grad,
+                                                          double *__restrict__ sigma)
+{
+    using C = WsCfg<NT>;
+    constexpr int NKS = 4 * NT;       // k-steps over the padded AO index
+    constexpr int NTW = (NT + 3) / 4; // column tiles per MFMA wave
+    constexpr int ATILE = WS_ROWS * C::LDA, XTILE = WS_ROWS * C::LDX;
+    __shared__ double As[WS_RING * ATILE];
+    __shared__ double Xs[2 * XTILE];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long ntile = (ngrid + WS_ROWS - 1) / WS_ROWS;
+    const long nloc = (ntile > (long)blockIdx.x) ? (ntile - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const long nstep = nloc + 2;
+
+    if (wave < 4) {
+        // ---------------------------------------------------------- MFMA role
+        const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+        const int nks = (nao + 3) >> 2; // k-steps that carry data
+        const bool two = NTW > 1 && wave + 4 < NT;
+        double dreg[NTW][NKS];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int tcol = min(wave + 4 * i, NT - 1); // clamped: an unowned tile is never used
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                dreg[i][ks] = Dp[(size_t)(4 * ks + lk) * C::NCOL + 16 * tcol + li];
+        }
+        for (long base = 0; base < nstep; base += WS_RING) {
+#pragma unroll
+            for (int u = 0; u < WS_RING; ++u) {
+                const long step = base + u;
+                if (step >= 1 && step <= nloc && wave < NT) { // X(step-1) from AO stage (u+3)%4
+                    const double *ap = As + ((u + 3) % WS_RING) * ATILE + li * C::LDA + lk;
+                    double *X = Xs + ((u + 1) & 1) * XTILE;
+                    d4 acc[NTW];
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        if (ks < NKS - 3 || ks < nks) {
+                            const double a = ap[4 * ks];
+                            acc[0] = mfma_f64(a, dreg[0][ks], acc[0]);
+                            if (NTW > 1) {
+                                if (two) acc[NTW - 1] = mfma_f64(a, dreg[NTW - 1][ks], acc[NTW - 1]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        X[(lk + 4 * r) * C::LDX + 16 * wave + li] = acc[0][r];
+                        if (NTW > 1) {
+                            if (two) X[(lk + 4 * r) * C::LDX + 16 * (wave + 4) + li] = acc[NTW - 1][r];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        // -------------------------------------------------------- loader role
+        __builtin_amdgcn_s_setprio(3); // see k_vxc_ws
+        const int lt = tid - 256, row = lt >> 4, seg = lt & 15;
+        double ph[2][2 * C::JN];                                           // AO of sub-tiles s, s+1
+        double pgx[2][2 * C::JN], pgy[2][2 * C::JN], pgz[2][2 * C::JN];   // gradients of s-2.., see below
+
+        auto row_of = [&](long s) { return (blockIdx.x + s * gridDim.x) * WS_ROWS + row; };
+        // unconditional issue with a clamped sub-tile index: see k_vxc_ws
+        const long plane = ngrid * (long)nao;
+        const unsigned voff = (unsigned)(row * nao + 2 * seg) * 8u;
+        auto issue_ao = [&](int set, long s) {
+            const long row0 = (blockIdx.x + min(s, nloc - 1) * gridDim.x) * WS_ROWS; // wave-uniform
+            buf_load_row<C::JN, VEC>(plane_tile_rsrc(ao, plane, row0 * nao), voff, ph[set]);
+        };
+        auto issue_grad = [&](int set, long s) {
+            const long e0 = (blockIdx.x + min(s, nloc - 1) * gridDim.x) * WS_ROWS * (long)nao;
+            buf_load_row<C::JN, VEC>(plane_tile_rsrc(gx, plane, e0), voff, pgx[set]);
+            buf_load_row<C::JN, VEC>(plane_tile_rsrc(gy, plane, e0), voff, pgy[set]);
+            buf_load_row<C::JN, VEC>(plane_tile_rsrc(gz, plane, e0), voff, pgz[set]);
+        };
+        issue_ao(0, 0);
+        issue_ao(1, 1);
+
+        for (long base = 0; base < nstep; base += WS_RING) {
+#pragma unroll
+            for (int u = 0; u < WS_RING; ++u) {
+                const long step = base + u;
+                const int set = u & 1;
+                // (a) AO(step) -> ring slot u, then refill the register set with AO(step+2)
+                {
+                    double *A = As + u * ATILE;
+#pragma unroll
+                    for (int j = 0; j < C::JN; ++j) {
+                        const int c = 32 * j + 2 * seg;
+                        if (c < C::NCOL)
+                            *reinterpret_cast<double2 *>(&A[row * C::LDA + c]) = make_double2(ph[set][2 * j], ph[set][2 * j + 1]);
+                    }
+                    issue_ao(set, step + 2);
+                }
+                // (b) row dots of sub-tile step-2: X from the X ring, AO from ring slot (u+2)%4,
+                //     gradients from register set `set` (loaded at step-2)
+                { // for step < 2 this runs on never-written LDS; nothing is stored (row_ok false)
+                    const long g = row_of(step - 2);
+                    const bool row_ok = step >= 2 && step - 2 < nloc && g < ngrid;
+                    const double *A = As + ((u + 2) % WS_RING) * ATILE;
+                    const double *X = Xs + (u & 1) * XTILE;
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < C::JN; ++j) {
+                        const int c = 32 * j + 2 * seg;
+                        if (c < C::NCOL) {
+                            const double2 x = *reinterpret_cast<const double2 *>(&X[row * C::LDX + c]);
+                            const double2 p = *reinterpret_cast<const double2 *>(&A[row * C::LDA + c]);
+                            s0 += x.x * p.x + x.y * p.y;
+                            if (GRAD) {
+                                // X columns >= nao are exact zeros (zero-padded Ds); rows past the grid read as 0
+                                s1 += x.x * pgx[set][2 * j] + x.y * pgx[set][2 * j + 1];
+                                s2 += x.x * pgy[set][2 * j] + x.y * pgy[set][2 * j + 1];
+                                s3 += x.x * pgz[set][2 * j] + x.y * pgz[set][2 * j + 1];
+                            }
+                        }
+                    }
+                    s0 = row16_sum(s0);
+                    if (GRAD) {
+                        s1 = row16_sum(s1);
+                        s2 = row16_sum(s2);
+                        s3 = row16_sum(s3);
+                    }
+                    if (seg == 0 && row_ok) {
+                        rho[g] = s0;
+                        if (GRAD) {
+                            const double ax = 2.0 * s1, ay = 2.0 * s2, az = 2.0 * s3;
+                            grad[3 * g + 0] = ax;
+                            grad[3 * g + 1] = ay;
+                            grad[3 * g + 2] = az;
+                            sigma[g] = ax * ax + ay * ay + az * az;
+                        }
+                    }
+                }
+                // (c) gradients of sub-tile `step` into the set just freed (consumed at step+2)
+                if (GRAD) issue_grad(set, step);
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// Sum of the per-workgroup slabs, 4 slab groups per element in parallel, fixed order.
+template <bool SYM>
+__global__ __launch_bounds__(256) void k_reduce_slabs4(int nao, int nslab,
+                                                       const double *__restrict__ slabs,
+                                                       double *__restrict__ V)
+{
+    __shared__ double part[4][64];
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    const size_t n2 = (size_t)nao * nao;
+    double s = 0.0;
+    if (e < (int)n2) {
+        const int a = e / nao, b = e - a * nao;
+        const int et = b * nao + a;
+        for (int k = grp; k < nslab; k += 4) {
+            double v = slabs[k * n2 + e];
+            if (SYM) v += slabs[k * n2 + et]; // (x + y) == (y + x): V comes out bitwise symmetric
+            s += v;
+        }
+    }
+    part[grp][el] = s;
+    __syncthreads();
+    if (grp == 0 && e < (int)n2) V[e] = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+}
+
+} // namespace qcdft
