@@ -13,6 +13,7 @@ Output = ONE JSON line on rank 0 (metric grid-points/s) carrying `roofline` for 
          the CPU oracle timed on a bounded slice of the same inputs; N=1, rank 0 only).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -33,7 +34,9 @@ WORKLOADS = {
     "anthracene_b3lyp_sto3g": ("B3LYP", 80, 294868),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-F64_MFMA_PEAK_TF = 78.6      # AMD datasheet fp64 matrix peak (the local guide lists no fp64 figure)
+F64_MFMA_PEAK_TF = 78.6      # AMD datasheet fp64 matrix peak (the local guide lists no fp64 figure); measured here:
+                             # 77.9 TF on constant operands at 2.39 GHz, ~59 TF on real data (clock drops to ~1.8 GHz),
+                             # profiles/r01_mfma_f64_probe2.txt and DESIGN.md
 SEED = 20260128
 
 
@@ -66,23 +69,61 @@ def kernel_model(name, xc, ngrid, nao):
     return 0.0, 0.0
 
 
-def cpu_baseline(xc, dm, ao, gr, w, sample):
+def host_cpu_share():
+    """CPUs this process may really use: affinity mask, cgroup quota, capped at 16 (the GPU box's
+    share for one GPU); os.cpu_count() reports the whole host (256 there)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(xc, dm, ao, gr, w, target_seconds):
+    """The OpenMP build of the CPU oracle (a port of the reference's loop structure,
+    dft_solver.cu:294-432 + B^T.AO) timed on a bounded slice of the same inputs."""
     import oracle                                   # test infrastructure: the checker, timed as the baseline
-    threads = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    threads = host_cpu_share()
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     oracle.build(omp=True)
     t = {"LDA": 0, "GGA": 1, "B3LYP": 2}[xc]
-    h = lambda a: None if a is None else a.cpu().numpy()
-    dm_h, ao_h, w_h = h(dm), h(ao[:sample]), h(w[:sample])
-    gr_h = None if gr is None else np.ascontiguousarray(h(gr[:, :sample]))
-    oracle.compute_xc(t, dm_h, ao_h[:256], w_h[:256], None if gr_h is None else gr_h[:, :256], omp=True)  # warm
-    t0 = time.perf_counter()
-    oracle.compute_xc(t, dm_h, ao_h, w_h, gr_h, omp=True)
-    dt = time.perf_counter() - t0
-    return {"value": sample / dt, "unit": "grid-points/s", "cores": int(os.environ["OMP_NUM_THREADS"]),
-            "kind": "port", "seconds": dt,
-            "sample": f"first {sample} grid points of the same inputs, OpenMP build of oracle/xc_oracle.c "
-                      f"(reference loop structure, dft_solver.cu:346-432)"}
+    ngrid = ao.shape[0]
+
+    def run(n):
+        h = lambda a: None if a is None else np.ascontiguousarray(a.cpu().numpy())
+        dm_h, ao_h, w_h = h(dm), h(ao[:n]), h(w[:n])
+        gr_h = None if gr is None else h(gr[:, :n])
+        t0 = time.perf_counter()
+        oracle.compute_xc(t, dm_h, ao_h, w_h, gr_h, omp=True)
+        return time.perf_counter() - t0
+
+    run(256)                                        # warm (library load, thread pool)
+    probe = min(4096, ngrid)
+    rate = probe / run(probe)
+    sample = int(min(ngrid, max(probe, rate * target_seconds)))
+    dt = run(sample)
+    return {"value": sample / dt, "unit": "grid-points/s", "cores": threads, "kind": "port",
+            "seconds": dt,
+            "sample": f"first {sample} of {ngrid} grid points of the same inputs, OpenMP build of "
+                      f"oracle/xc_oracle.c (reference loop structure, dft_solver.cu:294-432), "
+                      f"{threads} threads"}
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled
+    per the gfx950 correction, + WRITE_SIZE); None when no profile matches this workload."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload") == workload and kernel in d.get("kernels", {}):
+            best = {"hbm_bytes": d["kernels"][kernel]["hbm_bytes"], "source": os.path.basename(f)}
+    return best
 
 
 def main():
@@ -91,7 +132,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="benzene_gga_def2svp", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample", type=int, default=16384)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -161,7 +202,10 @@ def main():
         else:
             roof = {"bound": "mfma", "achieved": f_alg / t_dom / 1e12, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = None
+        tr = pmc_traffic(args.workload, dom)
+        roof["traffic"] = tr["hbm_bytes"] if tr else None
+        if tr:
+            roof["traffic_source"] = "profiles/" + tr["source"]
         roof.update({"kernel": dom, "kernel_ms": kern[dom], "alg_bytes": b_alg, "alg_flops": f_alg,
                      "other_bound_frac": (f_alg / t_dom / 1e12 / F64_MFMA_PEAK_TF) if roof["bound"] == "hbm"
                      else (b_alg / t_dom / 1e9 / HBM_PEAK_GBS)})
@@ -182,7 +226,7 @@ def main():
             "kernels_ms": kern, "exc": exc,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(xc, dm, ao, gr, w, min(args.cpu_sample, ngrid))
+            line["cpu_baseline"] = cpu_baseline(xc, dm, ao, gr, w, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

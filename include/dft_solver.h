@@ -117,10 +117,13 @@ int DFT_EvalAO(XCSolver *solver, long long ngrid, int nao, int nshell,
                unsigned long long d_ao_grad_ptr);
 
 /* Options: "quirks" (1 = reference formulas as shipped, default; 0 = corrected
- * VWN5 / PBE-c derivatives), "path" (0 = MFMA kernels, default;
- * 1 = plain-VALU validation kernels), "profile" (1 = record per-kernel HIP
- * events for DFT_GetTimings), "ksplit" (grid chunks of the Vxc contraction;
- * 0 = auto).  Returns 0 if the key is known. */
+ * VWN5 / PBE-c derivatives), "path" (0 = auto: wave-specialised
+ * persistent MFMA kernels for nao <= 128, generic MFMA kernels above; 1 =
+ * plain-VALU validation kernels; 2 = generic MFMA kernels always), "profile"
+ * (1 = record per-kernel HIP events for DFT_GetTimings), "ksplit" (grid chunks
+ * of the generic Vxc contraction; 0 = auto), "spin_wait" (1, default: the host
+ * polls the host-mapped Exc word written by the last kernel instead of sleeping
+ * in hipStreamSynchronize).  Returns 0 if the key is known. */
 int DFT_SetOption(XCSolver *solver, const char *key, double value);
 
 /* Run subsequent work on `hip_stream` (a hipStream_t cast to an integer);

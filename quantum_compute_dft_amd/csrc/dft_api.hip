@@ -51,7 +51,9 @@ struct XCSolver {
     int ksplit = 0;
     // workspace
     DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells;
-    double *h_exc = nullptr; // pinned
+    int spin_wait = 1; // poll the host-mapped Exc instead of sleeping in hipStreamSynchronize
+    double *h_exc = nullptr;   // pinned, host-mapped: the reduce kernel writes Exc here
+    double *h_exc_dev = nullptr; // device alias of h_exc
     std::string last_error;
     std::vector<Timing> timings;
     size_t n_timed = 0;
@@ -142,7 +144,7 @@ int auto_ksplit(const XCSolver *s, long ngrid, int nblk)
 
 // The sweep: everything on s->stream, Exc left in s->exc (device).
 bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *ao,
-              const double *ao_grad, const double *w, double *vxc)
+              const double *ao_grad, const double *w, double *vxc, bool want_host_exc)
 {
     s->last_error.clear();
     s->n_timed = 0;
@@ -182,8 +184,13 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
         !reserve(s, s->coef, sizeof(double) * ng * (gga ? 4 : 1), "hipMalloc(coef)") ||
         !reserve(s, s->partial, sizeof(double) * nxb, "hipMalloc(partial)") ||
         !reserve(s, s->slabs, sizeof(double) * (size_t)nslab * nao * nao, "hipMalloc(slabs)") ||
-        !reserve(s, s->exc, sizeof(double), "hipMalloc(exc)"))
+        false)
         return false;
+    if (!s->exc.p) { // [Exc double | ticket counter], zeroed once; the reduce kernel re-zeroes the ticket
+        if (!reserve(s, s->exc, 16, "hipMalloc(exc)") ||
+            !hip_ok(s, hipMemsetAsync(s->exc.p, 0, 16, s->stream), "memset(exc)"))
+            return false;
+    }
     if (gga && (!reserve(s, s->sigma, sizeof(double) * ng, "hipMalloc(sigma)") ||
                 !reserve(s, s->grad, sizeof(double) * 3 * ng, "hipMalloc(grad)")))
         return false;
@@ -196,7 +203,7 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
                  *gz = gga ? ao_grad + 2 * ng * nao : nullptr;
     hipStream_t st = s->stream;
 
-    {
+    if (!fast) { // the wave-specialised rho kernel symmetrises D in its prologue
         ScopedTimer t(s, "sym_dm");
         dim3 b(16, 16), g(NP / 16, NP / 16);
         hipLaunchKernelGGL(k_sym_dm, g, b, 0, st, nao, NP, dm, Dp);
@@ -206,7 +213,7 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
         const int vec16 = (nao % 2 == 0) && ((((uintptr_t)ao | (uintptr_t)gx | (uintptr_t)gy | (uintptr_t)gz) & 15) == 0);
         if (fast) {
             dim3 g((unsigned)nslab);
-#define QCDFT_RHO(G, V) QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_rho_ws<NT, G, V>), g, dim3(WS_THREADS), 0, st, ngrid, nao, ao, gx, gy, gz, Dp, rho, grad, sigma))
+#define QCDFT_RHO(G, V) QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_rho_ws<NT, G, V>), g, dim3(WS_THREADS), 0, st, ngrid, nao, ao, gx, gy, gz, dm, rho, grad, sigma))
             if (gga) { if (vec16) { QCDFT_RHO(true, true) } else { QCDFT_RHO(true, false) } }
             else     { if (vec16) { QCDFT_RHO(false, true) } else { QCDFT_RHO(false, false) } }
 #undef QCDFT_RHO
@@ -226,7 +233,6 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
         if (s->type == SOLVER_LDA)      hipLaunchKernelGGL(k_xc_points<0>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
         else if (s->type == SOLVER_GGA) hipLaunchKernelGGL(k_xc_points<1>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
         else                            hipLaunchKernelGGL(k_xc_points<2>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, nxb, partial, exc);
     }
     {
         ScopedTimer t(s, "vxc");
@@ -249,9 +255,10 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     }
     {
         ScopedTimer t(s, "reduce_vxc");
-        dim3 g((unsigned)(((size_t)nao * nao + 63) / 64));
-        if (s->type == SOLVER_B3LYP) hipLaunchKernelGGL(k_reduce_slabs4<true>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
-        else                         hipLaunchKernelGGL(k_reduce_slabs4<false>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
+        dim3 g((unsigned)(((size_t)nao * nao + 31) / 32)); // the last block to finish also completes Exc
+        double *hx = want_host_exc ? s->h_exc_dev : nullptr;
+        if (s->type == SOLVER_B3LYP) hipLaunchKernelGGL(k_reduce_slabs8<true>, g, dim3(256), 0, st, nao, nslab, slabs, vxc, nxb, partial, exc, hx, (unsigned *)(exc + 1));
+        else                         hipLaunchKernelGGL(k_reduce_slabs8<false>, g, dim3(256), 0, st, nao, nslab, slabs, vxc, nxb, partial, exc, hx, (unsigned *)(exc + 1));
     }
     return hip_ok(s, hipGetLastError(), "XC sweep launch");
 }
@@ -304,8 +311,13 @@ XCSolver *DFT_CreateSolver(int type)
             s->device_ok = true;
             s->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
-        if (s->device_ok && hipHostMalloc((void **)&s->h_exc, sizeof(double)) != hipSuccess) {
-            s->h_exc = nullptr;
+        if (s->device_ok) {
+            if (hipHostMalloc((void **)&s->h_exc, sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+                hipHostGetDevicePointer((void **)&s->h_exc_dev, s->h_exc, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                s->h_exc = nullptr;
+                s->h_exc_dev = nullptr;
+            }
         }
     } else {
         (void)hipGetLastError();
@@ -338,15 +350,29 @@ double DFT_ComputeXC64(XCSolver *s, long long ngrid, int nao, unsigned long long
 {
     if (!s) return 0.0;
     const double nan = std::numeric_limits<double>::quiet_NaN();
+    if (s->h_exc) *s->h_exc = nan; // before anything is enqueued: the last kernel overwrites it
     if (!xc_sweep(s, (long)ngrid, nao, (const double *)d_dm, (const double *)d_ao,
-                  (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc))
+                  (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc, true))
         return nan;
+    if (s->h_exc_dev) { // Exc is written into host-mapped memory by the block that finishes last
+        volatile double *hx = s->h_exc;
+        if (s->spin_wait) {
+            // every Vxc store of the launch is ordered before this value (see k_reduce_slabs8);
+            // the stream query bounds the spin if a kernel faulted or Exc really is NaN
+            for (unsigned spins = 1; std::isnan(*hx); ++spins) {
+                if ((spins & 0xFFF) == 0 && hipStreamQuery(s->stream) != hipErrorNotReady) break;
+                __builtin_ia32_pause();
+            }
+            if (!std::isnan(*hx)) return *hx;
+        }
+        if (!hip_ok(s, hipStreamSynchronize(s->stream), "synchronise")) return nan;
+        return *hx;
+    }
     double out = nan;
-    double *dst = s->h_exc ? s->h_exc : &out;
-    if (!hip_ok(s, hipMemcpyAsync(dst, s->exc.p, sizeof(double), hipMemcpyDeviceToHost, s->stream), "copy Exc") ||
+    if (!hip_ok(s, hipMemcpyAsync(&out, s->exc.p, sizeof(double), hipMemcpyDeviceToHost, s->stream), "copy Exc") ||
         !hip_ok(s, hipStreamSynchronize(s->stream), "synchronise"))
         return nan;
-    return *dst;
+    return out;
 }
 
 double DFT_ComputeXC(XCSolver *s, int ngrid, int nao, unsigned long long d_dm,
@@ -363,7 +389,7 @@ int DFT_ComputeXCAsync(XCSolver *s, long long ngrid, int nao, unsigned long long
 {
     if (!s) return -1;
     if (!xc_sweep(s, (long)ngrid, nao, (const double *)d_dm, (const double *)d_ao,
-                  (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc))
+                  (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc, false))
         return -1;
     if (d_exc && !hip_ok(s, hipMemcpyAsync((void *)d_exc, s->exc.p, sizeof(double), hipMemcpyDeviceToDevice, s->stream), "copy Exc"))
         return -1;
@@ -455,6 +481,7 @@ int DFT_SetOption(XCSolver *s, const char *key, double value)
     if (!strcmp(key, "quirks")) { s->quirks = value != 0.0; return 0; }
     if (!strcmp(key, "path")) { s->path = (int)value; return 0; }
     if (!strcmp(key, "profile")) { s->profile = value != 0.0; return 0; }
+    if (!strcmp(key, "spin_wait")) { s->spin_wait = value != 0.0; return 0; }
     if (!strcmp(key, "ksplit")) { s->ksplit = value > 0 ? (int)value : 0; return 0; }
     return -1;
 }

@@ -5,9 +5,9 @@
 // Replaces the reference's thread-per-grid-point kernels (src/dft_solver.cu):
 //   get_rho_kernel :294-307, get_rho_sigma_kernel_planar :346-380   -> k_rho_*
 //   lda/gga/b3lyp_fused_kernel :309-344,:382-432,:434-513 (both passes)
-//   + reduce_sum_kernel :285-292                                    -> k_xc_points, k_sum_partials
+//   + reduce_sum_kernel :285-292                                    -> k_xc_points, k_reduce_slabs8 (last block)
 //   B matrix + cublasDgemm :541-548,:580,:616,:663                  -> k_vxc_* (B never materialised)
-//   symmetrize_matrix_kernel :515-527                               -> k_reduce_slabs<true>
+//   symmetrize_matrix_kernel :515-527                               -> k_reduce_slabs8<true> (xc_ws_kernels.hpp)
 //
 // Formulation (identical result, different arithmetic order):
 //   Ds  = (D + D^T)/2                       (exact for any D: rho and grad rho only see the symmetric part)
@@ -241,22 +241,6 @@ __global__ __launch_bounds__(256) void k_xc_points(long ngrid, const double *__r
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// Fixed-order sum of the per-block partials (one block).
-__global__ __launch_bounds__(256) void k_sum_partials(long n, const double *__restrict__ partial,
-                                                      double *__restrict__ out)
-{
-    __shared__ double red[256];
-    double s = 0.0;
-    for (long i = threadIdx.x; i < n; i += 256) s += partial[i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int m = 128; m >= 1; m >>= 1) {
-        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = red[0];
-}
-
 // ---------------------------------------------------------------- Vxc ------
 // blockIdx.x = grid chunk, .y/.z = 128-wide blocks of the a / b index.
 // Per 32 grid points: Q[g][a] = sum_c coef_c[g] * plane_c[g][a] and P[g][b] = AO[g][b]
@@ -375,28 +359,6 @@ __global__ __launch_bounds__(256) void k_vxc_valu(long ngrid, int nao, long chun
         }
         slab[e] = s;
     }
-}
-
-// V = sum over chunk slabs in fixed order; SYM adds the transpose (M + M^T,
-// what symmetrize_matrix_kernel does for B3LYP, src/dft_solver.cu:515-527).
-template <bool SYM>
-__global__ __launch_bounds__(256) void k_reduce_slabs(int nao, int nslab,
-                                                      const double *__restrict__ slabs,
-                                                      double *__restrict__ V)
-{
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= nao * nao) return;
-    const size_t n2 = (size_t)nao * nao;
-    double s = 0.0;
-    for (int k = 0; k < nslab; ++k) s += slabs[k * n2 + e];
-    if (SYM) {
-        const int a = e / nao, b = e - a * nao;
-        const int et = b * nao + a;
-        double t = 0.0;
-        for (int k = 0; k < nslab; ++k) t += slabs[k * n2 + et];
-        s += t;
-    }
-    V[e] = s;
 }
 
 } // namespace qcdft

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
                                                           const double *__restrict__ gx,
                                                           const double *__restrict__ gy,
                                                           const double *__restrict__ gz,
-                                                          const double *__restrict__ Dp,
+                                                          const double *__restrict__ dm,
                                                           double *__restrict__ rho,
                                                           double *__restrict__ grad,
                                                           double *__restrict__ sigma)
@@ -331,9 +331,17 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             const int tcol = min(wave + 4 * i, NT - 1); // clamped: an unowned tile is never used
+            // Ds = (D + D^T)/2, zero outside nao x nao: formed here, once per wave, straight from
+            // the caller's matrix (saves the separate symmetrisation launch of the generic path)
+            const int n = 16 * tcol + li;
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-                dreg[i][ks] = Dp[(size_t)(4 * ks + lk) * C::NCOL + 16 * tcol + li];
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int k = 4 * ks + lk;
+                const bool in = k < nao && n < nao;
+                const int kc = in ? k : 0, nc = in ? n : 0;
+                const double v = 0.5 * (dm[(size_t)kc * nao + nc] + dm[(size_t)nc * nao + kc]);
+                dreg[i][ks] = in ? v : 0.0;
+            }
         }
         for (long base = 0; base < nstep; base += WS_RING) {
 #pragma unroll
@@ -454,29 +462,66 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
     }
 }
 
-// Sum of the per-workgroup slabs, 4 slab groups per element in parallel, fixed order.
+// V = sum of the per-workgroup slabs in a fixed order (bitwise reproducible): 32 elements x 8
+// slab groups per block, then a fixed tree over the groups.  SYM adds the transpose (M + M^T,
+// what symmetrize_matrix_kernel does for B3LYP, src/dft_solver.cu:515-527).
+// The block that FINISHES LAST (device-scope ticket after its V stores are fenced) completes
+// Exc: fixed-order sum of the per-block partials of k_xc_points (reduce_sum_kernel,
+// src/dft_solver.cu:285-292, made deterministic), stored to the device scalar and, if given,
+// to host-mapped memory.  Because that store is ordered after every V store of the launch,
+// the host may return from DFT_ComputeXC as soon as it sees the value (no copy launch, no
+// sleeping synchronise).
 template <bool SYM>
-__global__ __launch_bounds__(256) void k_reduce_slabs4(int nao, int nslab,
+__global__ __launch_bounds__(256) void k_reduce_slabs8(int nao, int nslab,
                                                        const double *__restrict__ slabs,
-                                                       double *__restrict__ V)
+                                                       double *__restrict__ V, long npart,
+                                                       const double *__restrict__ partial,
+                                                       double *__restrict__ exc_dev,
+                                                       double *exc_host, unsigned *ticket)
 {
-    __shared__ double part[4][64];
-    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + el;
+    __shared__ double part[256];
+    __shared__ bool last;
     const size_t n2 = (size_t)nao * nao;
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const size_t e = (size_t)blockIdx.x * 32 + el;
     double s = 0.0;
-    if (e < (int)n2) {
-        const int a = e / nao, b = e - a * nao;
-        const int et = b * nao + a;
-        for (int k = grp; k < nslab; k += 4) {
+    if (e < n2) {
+        const int a = (int)(e / nao), b = (int)(e - (size_t)a * nao);
+        const size_t et = (size_t)b * nao + a;
+#pragma unroll 4
+        for (int k = grp; k < nslab; k += 8) {
             double v = slabs[k * n2 + e];
             if (SYM) v += slabs[k * n2 + et]; // (x + y) == (y + x): V comes out bitwise symmetric
             s += v;
         }
     }
-    part[grp][el] = s;
+    part[threadIdx.x] = s;
     __syncthreads();
-    if (grp == 0 && e < (int)n2) V[e] = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+    if (grp == 0 && e < n2) {
+        const double *p = &part[el];
+        V[e] = ((p[0] + p[32]) + (p[64] + p[96])) + ((p[128] + p[160]) + (p[192] + p[224]));
+        __threadfence(); // this block's V stores are visible device-wide before its ticket
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    double x = 0.0;
+    for (long i = threadIdx.x; i < npart; i += 256) x += partial[i];
+    part[threadIdx.x] = x;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) part[threadIdx.x] += part[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *ticket = 0; // ready for the next call on this stream
+        exc_dev[0] = part[0];
+        if (exc_host) {
+            *(volatile double *)exc_host = part[0];
+            __threadfence_system();
+        }
+    }
 }
 
 } // namespace qcdft
