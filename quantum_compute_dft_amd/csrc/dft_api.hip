@@ -239,9 +239,10 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
         const int vec16 = (nao % 2 == 0) && ((((uintptr_t)ao | (uintptr_t)gx | (uintptr_t)gy | (uintptr_t)gz) & 15) == 0);
         if (fast) {
             dim3 g((unsigned)nslab);
-#define QCDFT_VXC(G, V) QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_vxc_ws<NT, G, V>), g, dim3(WS_THREADS), 0, st, ngrid, nao, ao, gx, gy, gz, coef, slabs))
-            if (gga) { if (vec16) { QCDFT_VXC(true, true) } else { QCDFT_VXC(true, false) } }
-            else     { if (vec16) { QCDFT_VXC(false, true) } else { QCDFT_VXC(false, false) } }
+#define QCDFT_VXC(G, V, S) QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_vxc_ws<NT, G, V, S>), g, dim3(WS_THREADS), 0, st, ngrid, nao, ao, gx, gy, gz, coef, slabs))
+            if (s->type == SOLVER_B3LYP) { if (vec16) { QCDFT_VXC(true, true, true) } else { QCDFT_VXC(true, false, true) } }
+            else if (gga) { if (vec16) { QCDFT_VXC(true, true, false) } else { QCDFT_VXC(true, false, false) } }
+            else          { if (vec16) { QCDFT_VXC(false, true, false) } else { QCDFT_VXC(false, false, false) } }
 #undef QCDFT_VXC
         } else if (s->path != 1) {
             dim3 g((unsigned)nslab, nblk, nblk);
@@ -257,7 +258,7 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
         ScopedTimer t(s, "reduce_vxc");
         dim3 g((unsigned)(((size_t)nao * nao + 31) / 32)); // the last block to finish also completes Exc
         double *hx = want_host_exc ? s->h_exc_dev : nullptr;
-        if (s->type == SOLVER_B3LYP) hipLaunchKernelGGL(k_reduce_slabs8<true>, g, dim3(256), 0, st, nao, nslab, slabs, vxc, nxb, partial, exc, hx, (unsigned *)(exc + 1));
+        if (s->type == SOLVER_B3LYP && !fast) hipLaunchKernelGGL(k_reduce_slabs8<true>, g, dim3(256), 0, st, nao, nslab, slabs, vxc, nxb, partial, exc, hx, (unsigned *)(exc + 1));
         else                         hipLaunchKernelGGL(k_reduce_slabs8<false>, g, dim3(256), 0, st, nao, nslab, slabs, vxc, nxb, partial, exc, hx, (unsigned *)(exc + 1));
     }
     return hip_ok(s, hipGetLastError(), "XC sweep launch");
@@ -282,12 +283,19 @@ void jk(XCSolver *s, int nao, const double *eri, const double *dm, double *J, do
     double *jp = (double *)s->jpart.p, *kp = (double *)s->kpart.p;
     dim3 g(ncb, n * jsplit);
     hipStream_t st = s->stream;
-    if (J && K)  hipLaunchKernelGGL((k_jk_stream<true, true>), g, dim3(256), 0, st, n, KB, jsplit, eri, dm, jp, kp);
-    else if (J)  hipLaunchKernelGGL((k_jk_stream<true, false>), g, dim3(256), 0, st, n, KB, jsplit, eri, dm, jp, kp);
-    else         hipLaunchKernelGGL((k_jk_stream<false, true>), g, dim3(256), 0, st, n, KB, jsplit, eri, dm, jp, kp);
-    dim3 gr((unsigned)((N2 + 255) / 256));
-    if (J) hipLaunchKernelGGL(k_sum_slabs, gr, dim3(256), 0, st, N2, nslabJ, N2, jp, J);
-    if (K) hipLaunchKernelGGL(k_sum_slabs, gr, dim3(256), 0, st, N2, jsplit, N2, kp, K);
+    const bool vec = (n % 2 == 0) && (((uintptr_t)eri & 15) == 0);
+#define QCDFT_JK(WJ, WK)                                                                                                  \
+    do {                                                                                                                  \
+        if (vec) hipLaunchKernelGGL((k_jk_stream<WJ, WK, true>), g, dim3(256), 0, st, n, KB, jsplit, eri, dm, jp, kp);    \
+        else     hipLaunchKernelGGL((k_jk_stream<WJ, WK, false>), g, dim3(256), 0, st, n, KB, jsplit, eri, dm, jp, kp);   \
+    } while (0)
+    if (J && K) QCDFT_JK(true, true);
+    else if (J) QCDFT_JK(true, false);
+    else        QCDFT_JK(false, true);
+#undef QCDFT_JK
+    dim3 gr((unsigned)((N2 + 31) / 32));
+    if (J) hipLaunchKernelGGL(k_sum_slabs8, gr, dim3(256), 0, st, N2, nslabJ, N2, jp, J);
+    if (K) hipLaunchKernelGGL(k_sum_slabs8, gr, dim3(256), 0, st, N2, jsplit, N2, kp, K);
     hip_ok(s, hipGetLastError(), "J/K launch");
 }
 

@@ -21,7 +21,9 @@ namespace qcdft {
 
 constexpr int JK_COLS = 1024; // columns per workgroup (4 per thread)
 
-template <bool WANT_J, bool WANT_K>
+// VEC (n even: every ERI row is 16-byte aligned): each thread owns column pairs
+// (2t, 2t+1) + 512q and reads them with one 16-byte load; otherwise single columns t + 256q.
+template <bool WANT_J, bool WANT_K, bool VEC>
 __global__ __launch_bounds__(256) void k_jk_stream(int n, int KB, int jsplit,
                                                    const double *__restrict__ eri,
                                                    const double *__restrict__ dm,
@@ -35,45 +37,51 @@ __global__ __launch_bounds__(256) void k_jk_stream(int n, int KB, int jsplit,
     const int jper = (n + jsplit - 1) / jsplit;
     const int jlo = js * jper, jhi = min(n, jlo + jper);
     const int klo = blockIdx.x * KB, khi = min(n, klo + KB);
-    const int ncol = (khi - klo) * n;       // columns of this block
+    const int ncol = (khi - klo) * n;       // columns of this block (even when VEC)
     const size_t cbase = (size_t)klo * n;   // first column
 
     double ja[4] = {0, 0, 0, 0}, ka[4] = {0, 0, 0, 0};
-    int lcol[4];
+    int col[4], lcol[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int c = tid + 256 * q;
-        lcol[q] = (c < ncol) ? (c % n) : 0; // l index of column c
+        col[q] = VEC ? 2 * tid + (q & 1) + 512 * (q >> 1) : tid + 256 * q;
+        lcol[q] = (col[q] < ncol) ? (col[q] % n) : 0; // l index of the column
     }
     for (int j = jlo; j < jhi; ++j) {
         const size_t r = (size_t)i * n + j;
         const double *row = eri + r * N2 + cbase;
         const double dr = WANT_J ? dm[r] : 0.0;
         const double *drow = dm + (size_t)j * n;
+        double e[4] = {0, 0, 0, 0};
+        if (VEC) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (col[2 * h] < ncol) { // ncol even: the pair is inside together
+                    const double2 v = *reinterpret_cast<const double2 *>(row + col[2 * h]);
+                    e[2 * h] = v.x;
+                    e[2 * h + 1] = v.y;
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (col[q] < ncol) e[q] = row[col[q]];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int c = tid + 256 * q;
-            if (c < ncol) {
-                const double e = row[c];
-                if (WANT_J) ja[q] += e * dr;
-                if (WANT_K) ka[q] += e * drow[lcol[q]];
-            }
+            if (WANT_J) ja[q] += e[q] * dr;
+            if (WANT_K) ka[q] += e[q] * drow[lcol[q]];
         }
     }
     if (WANT_J) {
         double *jp = Jpart + (size_t)blockIdx.y * N2 + cbase;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = tid + 256 * q;
-            if (c < ncol) jp[c] = ja[q];
-        }
+        for (int q = 0; q < 4; ++q)
+            if (col[q] < ncol) jp[col[q]] = ja[q];
     }
     if (WANT_K) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = tid + 256 * q;
-            if (c < ncol) T[c] = ka[q];
-        }
+        for (int q = 0; q < 4; ++q)
+            if (col[q] < ncol) T[col[q]] = ka[q];
         __syncthreads();
         if (tid < khi - klo) {
             double s = 0.0;
@@ -84,16 +92,25 @@ __global__ __launch_bounds__(256) void k_jk_stream(int n, int KB, int jsplit,
     }
 }
 
-// out[e] = sum_s part[s*stride + e], fixed order.
-__global__ __launch_bounds__(256) void k_sum_slabs(size_t nelem, int nslab, size_t stride,
-                                                   const double *__restrict__ part,
-                                                   double *__restrict__ out)
+// out[e] = sum_s part[s*stride + e] in a fixed order: 32 elements x 8 slab groups per block.
+__global__ __launch_bounds__(256) void k_sum_slabs8(size_t nelem, int nslab, size_t stride,
+                                                    const double *__restrict__ part,
+                                                    double *__restrict__ out)
 {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= nelem) return;
+    __shared__ double red[256];
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const size_t e = (size_t)blockIdx.x * 32 + el;
     double s = 0.0;
-    for (int k = 0; k < nslab; ++k) s += part[(size_t)k * stride + e];
-    out[e] = s;
+    if (e < nelem) {
+#pragma unroll 4
+        for (int k = grp; k < nslab; k += 8) s += part[(size_t)k * stride + e];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && e < nelem) {
+        const double *p = &red[el];
+        out[e] = ((p[0] + p[32]) + (p[64] + p[96])) + ((p[128] + p[160]) + (p[192] + p[224]));
+    }
 }
 
 } // namespace qcdft

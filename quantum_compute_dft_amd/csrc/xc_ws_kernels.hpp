@@ -117,7 +117,9 @@ __device__ __forceinline__ double row16_sum(double v)
 
 // ------------------------------------------------------------------ Vxc ----
 // V[a][b] += sum_g Q[g][a] P[g][b],  Q = sum_c coef_c * plane_c,  P = AO.
-template <int NT, bool GRAD, bool VEC>
+// SYM: the workgroup writes M + M^T of its partial (B3LYP, symmetrize_matrix_kernel
+// src/dft_solver.cu:515-527) -- transposed through LDS so the slab reduce stays a coalesced sum.
+template <int NT, bool GRAD, bool VEC, bool SYM>
 __global__ __launch_bounds__(WS_THREADS, 2) void k_vxc_ws(long ngrid, int nao,
                                                           const double *__restrict__ ao,
                                                           const double *__restrict__ gx,
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_vxc_ws(long ngrid, int nao,
     using C = WsCfg<NT>;
     constexpr int TILE = WS_ROWS * C::LDX;
     constexpr int NTW = (NT + 1) / 2; // MFMA tiles per wave along each of a, b
-    __shared__ double Ps[WS_RING * TILE];
-    __shared__ double Qs[WS_RING * TILE];
+    __shared__ double ring[2 * WS_RING * TILE];
+    double *const Ps = ring, *const Qs = ring + WS_RING * TILE;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -193,18 +195,34 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_vxc_ws(long ngrid, int nao,
         if ((tid & 63) == 0) { g_stamps[(blockIdx.x * 8 + wave) * 4 + 0] = st_acc[0]; g_stamps[(blockIdx.x * 8 + wave) * 4 + 1] = st_acc[1]; }
 #endif
         double *slab = slabs + (size_t)blockIdx.x * nao * nao;
+        if (!SYM) {
 #pragma unroll
-        for (int i = 0; i < NTW; ++i)
+            for (int i = 0; i < NTW; ++i)
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                if (i >= na || j >= nb) continue;
-                const int b = 16 * (wb + 2 * j) + li;
+                for (int j = 0; j < NTW; ++j) {
+                    if (i >= na || j >= nb) continue;
+                    const int b = 16 * (wb + 2 * j) + li;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int a = 16 * (wa + 2 * i) + lk + 4 * r;
-                    if (a < nao && b < nao) slab[(size_t)a * nao + b] = acc[i][j][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int a = 16 * (wa + 2 * i) + lk + 4 * r;
+                        if (a < nao && b < nao) slab[(size_t)a * nao + b] = acc[i][j][r];
+                    }
                 }
-            }
+        } else {
+            // the ring is dead after the last barrier of the loop: reuse it as M[a][b], ld NCOL+1
+            constexpr int LDM = C::NCOL + 1;
+            static_assert(LDM * C::NCOL <= 2 * WS_RING * TILE, "M tile must fit in the ring");
+            double *M = ring;
+#pragma unroll
+            for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    if (i >= na || j >= nb) continue;
+                    const int b = 16 * (wb + 2 * j) + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) M[(16 * (wa + 2 * i) + lk + 4 * r) * LDM + b] = acc[i][j][r];
+                }
+        }
     } else {
         // -------------------------------------------------------- loader role
         // The loader stream is short (~200 instructions per step) but latency-critical; at equal
@@ -292,6 +310,16 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_vxc_ws(long ngrid, int nao,
 #ifdef QCDFT_STAMPS
         if ((tid & 63) == 0) { for (int q = 0; q < 4; ++q) g_stamps[(blockIdx.x * 8 + wave) * 4 + q] = st_acc[q]; }
 #endif
+    }
+    if (SYM) { // all eight waves: slab = M + M^T, coalesced stores
+        constexpr int LDM = C::NCOL + 1;
+        const double *M = ring;
+        __syncthreads();
+        double *slab = slabs + (size_t)blockIdx.x * nao * nao;
+        for (int e = tid; e < nao * nao; e += WS_THREADS) {
+            const int a = e / nao, b = e - a * nao;
+            slab[e] = M[a * LDM + b] + M[b * LDM + a]; // (x + y) == (y + x): bitwise symmetric
+        }
     }
 }
 
@@ -471,7 +499,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
 // to host-mapped memory.  Because that store is ordered after every V store of the launch,
 // the host may return from DFT_ComputeXC as soon as it sees the value (no copy launch, no
 // sleeping synchronise).
-template <bool SYM>
+template <bool SYM> // SYM only for slabs of the generic path (the wave-specialised kernel pre-symmetrises)
 __global__ __launch_bounds__(256) void k_reduce_slabs8(int nao, int nslab,
                                                        const double *__restrict__ slabs,
                                                        double *__restrict__ V, long npart,

@@ -13,7 +13,7 @@ int main(){
   hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for(int rep=0;rep<3;rep++){
     hipEventRecord(e0,0);
-    hipLaunchKernelGGL((k_vxc_ws<8,true,true>),dim3(256),dim3(512),0,0,ngrid,nao,d,d+plane,d+2*plane,d+3*plane,coef,slabs);
+    hipLaunchKernelGGL((k_vxc_ws<8,true,true,false>),dim3(256),dim3(512),0,0,ngrid,nao,d,d+plane,d+2*plane,d+3*plane,coef,slabs);
     hipEventRecord(e1,0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1);
     std::vector<unsigned long long> st(256*8*4); hipMemcpyFromSymbol(st.data(),HIP_SYMBOL(g_stamps),st.size()*8);
     double m_work=0,m_bar=0,l_wait=0,l_work=0,l_bar=0,l_q=0;
