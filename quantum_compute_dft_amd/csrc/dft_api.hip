@@ -20,6 +20,7 @@
 #include "../../include/dft_solver.h"
 #include "ao_kernels.hpp"
 #include "jk_kernels.hpp"
+#include "xc_big_kernels.hpp"
 #include "xc_ws_kernels.hpp"
 #include "xc_kernels.hpp"
 
@@ -50,7 +51,7 @@ struct XCSolver {
     int profile = 0;
     int ksplit = 0;
     // workspace
-    DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells;
+    DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells, msym;
     int spin_wait = 1; // poll the host-mapped Exc instead of sleeping in hipStreamSynchronize
     double *h_exc = nullptr;   // pinned, host-mapped: the reduce kernel writes Exc here
     double *h_exc_dev = nullptr; // device alias of h_exc
@@ -164,10 +165,20 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     const int NP = ((nao + 15) / 16) * 16;
     const int nblk = (nao + 127) / 128;
     const bool fast = s->path == 0 && nao <= 128;
+    const bool big = s->path == 0 && nao > 128;
     const int ntv = NP / 16;
     int nslab;
     long chunk = 0;
-    if (fast) {
+    const int nA = (nao + BG_BM - 1) / BG_BM, nB = (nao + BG_BN - 1) / BG_BN, npair = nA * nB;
+    if (big) {
+        // split-K over grid chunks; chunks are dealt to XCDs (blockIdx % 8), so ksplit is a multiple of 8
+        long per_xcd = std::max(1, (s->num_cu / 8) / npair);
+        const long max_chunks = (ngrid + BG_BK - 1) / BG_BK;
+        while (per_xcd > 1 && 8 * per_xcd > max_chunks) per_xcd >>= 1;
+        nslab = (int)(8 * per_xcd);
+        chunk = (ngrid + nslab - 1) / nslab;
+        chunk = ((chunk + BG_BK - 1) / BG_BK) * BG_BK;
+    } else if (fast) {
         const long ntile = (ngrid + WS_ROWS - 1) / WS_ROWS;
         nslab = (int)std::min<long>(s->num_cu, ntile); // one persistent, wave-specialised workgroup per CU
     } else {
@@ -186,11 +197,7 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
         !reserve(s, s->slabs, sizeof(double) * (size_t)nslab * nao * nao, "hipMalloc(slabs)") ||
         false)
         return false;
-    if (!s->exc.p) { // [Exc double | ticket counter], zeroed once; the reduce kernel re-zeroes the ticket
-        if (!reserve(s, s->exc, 16, "hipMalloc(exc)") ||
-            !hip_ok(s, hipMemsetAsync(s->exc.p, 0, 16, s->stream), "memset(exc)"))
-            return false;
-    }
+    if (!reserve(s, s->exc, sizeof(double), "hipMalloc(exc)")) return false;
     if (gga && (!reserve(s, s->sigma, sizeof(double) * ng, "hipMalloc(sigma)") ||
                 !reserve(s, s->grad, sizeof(double) * 3 * ng, "hipMalloc(grad)")))
         return false;
@@ -217,6 +224,12 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
             if (gga) { if (vec16) { QCDFT_RHO(true, true) } else { QCDFT_RHO(true, false) } }
             else     { if (vec16) { QCDFT_RHO(false, true) } else { QCDFT_RHO(false, false) } }
 #undef QCDFT_RHO
+        } else if (big) {
+            dim3 g((unsigned)((ngrid + BG_BM - 1) / BG_BM));
+            if (gga) { if (vec16) hipLaunchKernelGGL((k_rho_big<true, true>), g, dim3(BG_THREADS), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
+                       else       hipLaunchKernelGGL((k_rho_big<true, false>), g, dim3(BG_THREADS), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma); }
+            else     { if (vec16) hipLaunchKernelGGL((k_rho_big<false, true>), g, dim3(BG_THREADS), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
+                       else       hipLaunchKernelGGL((k_rho_big<false, false>), g, dim3(BG_THREADS), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma); }
         } else if (s->path != 1) {
             dim3 g((unsigned)((ngrid + 63) / 64));
             if (gga) hipLaunchKernelGGL(k_rho_mfma<true>, g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
@@ -244,6 +257,12 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
             else if (gga) { if (vec16) { QCDFT_VXC(true, true, false) } else { QCDFT_VXC(true, false, false) } }
             else          { if (vec16) { QCDFT_VXC(false, true, false) } else { QCDFT_VXC(false, false, false) } }
 #undef QCDFT_VXC
+        } else if (big) {
+            dim3 g((unsigned)(nslab * npair));
+            if (gga) { if (vec16) hipLaunchKernelGGL((k_vxc_big<true, true>), g, dim3(BG_THREADS), 0, st, ngrid, nao, chunk, nB, npair, ao, gx, gy, gz, coef, slabs);
+                       else       hipLaunchKernelGGL((k_vxc_big<true, false>), g, dim3(BG_THREADS), 0, st, ngrid, nao, chunk, nB, npair, ao, gx, gy, gz, coef, slabs); }
+            else     { if (vec16) hipLaunchKernelGGL((k_vxc_big<false, true>), g, dim3(BG_THREADS), 0, st, ngrid, nao, chunk, nB, npair, ao, gx, gy, gz, coef, slabs);
+                       else       hipLaunchKernelGGL((k_vxc_big<false, false>), g, dim3(BG_THREADS), 0, st, ngrid, nao, chunk, nB, npair, ao, gx, gy, gz, coef, slabs); }
         } else if (s->path != 1) {
             dim3 g((unsigned)nslab, nblk, nblk);
             if (gga) hipLaunchKernelGGL(k_vxc_mfma<true>, g, dim3(256), 0, st, ngrid, nao, chunk, ao, gx, gy, gz, coef, slabs);
@@ -256,10 +275,21 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     }
     {
         ScopedTimer t(s, "reduce_vxc");
-        dim3 g((unsigned)(((size_t)nao * nao + 31) / 32)); // the last block to finish also completes Exc
-        double *hx = want_host_exc ? s->h_exc_dev : nullptr;
-        if (s->type == SOLVER_B3LYP && !fast) hipLaunchKernelGGL(k_reduce_slabs8<true>, g, dim3(256), 0, st, nao, nslab, slabs, vxc, nxb, partial, exc, hx, (unsigned *)(exc + 1));
-        else                         hipLaunchKernelGGL(k_reduce_slabs8<false>, g, dim3(256), 0, st, nao, nslab, slabs, vxc, nxb, partial, exc, hx, (unsigned *)(exc + 1));
+        dim3 g((unsigned)(((size_t)nao * nao + 31) / 32));
+        const bool b3 = s->type == SOLVER_B3LYP;
+        if (b3 && big) { // plain reduce into M, then tiled M + M^T
+            if (!reserve(s, s->msym, sizeof(double) * (size_t)nao * nao, "hipMalloc(M)")) return false;
+            double *M = (double *)s->msym.p;
+            hipLaunchKernelGGL(k_reduce_slabs8<false>, g, dim3(256), 0, st, nao, nslab, slabs, M);
+            const int nt = (nao + 31) / 32;
+            hipLaunchKernelGGL(k_symmetrize, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, nao, M, vxc);
+        } else if (b3 && !fast) {
+            hipLaunchKernelGGL(k_reduce_slabs8<true>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
+        } else { // wave-specialised slabs are already symmetrised for B3LYP
+            hipLaunchKernelGGL(k_reduce_slabs8<false>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
+        }
+        // last launch of the call: Exc to the device scalar and to host-mapped memory
+        hipLaunchKernelGGL(k_finish_exc, dim3(1), dim3(256), 0, st, nxb, partial, exc, want_host_exc ? s->h_exc_dev : nullptr);
     }
     return hip_ok(s, hipGetLastError(), "XC sweep launch");
 }
@@ -340,7 +370,7 @@ void DFT_DestroySolver(XCSolver *s)
     if (s->device_ok) {
         (void)hipStreamSynchronize(s->stream);
         DevBuf *bufs[] = {&s->dsym, &s->rho, &s->sigma, &s->grad, &s->coef, &s->partial,
-                          &s->slabs, &s->exc, &s->jpart, &s->kpart, &s->shells};
+                          &s->slabs, &s->exc, &s->jpart, &s->kpart, &s->shells, &s->msym};
         for (DevBuf *b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (s->h_exc) (void)hipHostFree(s->h_exc);
@@ -362,10 +392,10 @@ double DFT_ComputeXC64(XCSolver *s, long long ngrid, int nao, unsigned long long
     if (!xc_sweep(s, (long)ngrid, nao, (const double *)d_dm, (const double *)d_ao,
                   (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc, true))
         return nan;
-    if (s->h_exc_dev) { // Exc is written into host-mapped memory by the block that finishes last
+    if (s->h_exc_dev) { // Exc is written into host-mapped memory by the call's last kernel
         volatile double *hx = s->h_exc;
         if (s->spin_wait) {
-            // every Vxc store of the launch is ordered before this value (see k_reduce_slabs8);
+            // stream order puts k_finish_exc after every Vxc store of the call;
             // the stream query bounds the spin if a kernel faulted or Exc really is NaN
             for (unsigned spins = 1; std::isnan(*hx); ++spins) {
                 if ((spins & 0xFFF) == 0 && hipStreamQuery(s->stream) != hipErrorNotReady) break;

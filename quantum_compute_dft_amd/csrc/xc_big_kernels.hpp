@@ -1,0 +1,341 @@
+// Contraction kernels for nao > 128 (Anthracene/def2-SVP 246, def2-TZVP 494, C33.../def2-SVP
+// 1150): the sweep is fp64-MFMA-bound there (AI 60-140 flop/B), so these are classic LDS-tiled
+// GEMM tiles -- 512 threads = 8 waves in a 2x4 grid, workgroup tile 128 x 256, wave tile
+// 64 x 64 = 4x4 MFMA tiles (128 accumulator VGPRs), BK = 16, double-buffered LDS, next stage's
+// global loads issued before the current stage's MFMAs (in-wave staging: ~30 non-fp64
+// instructions per 64 MFMAs).  Plane tiles are read with range-checked buffer loads
+// (xc_ws_kernels.hpp): rows past the grid arrive as zeros, columns past nao only ever meet
+// exact zeros (zero-padded Ds) or discarded output tiles.
+//
+//   k_rho_big : X = AO . Ds tile by tile (128 x 128, wave tile 64 x 32); after each column block the X tile goes through
+//               LDS in four 32-row slabs so the row dots (rho, grad rho) run in the coalesced
+//               (row, seg) mapping; partial row sums stay in registers across column blocks.
+//   k_vxc_big : V[a-block 128][b-block 256] += Q^T . AO over one grid chunk, Q formed in
+//               registers from the four planes while staging.  Workgroups that share a grid
+//               chunk are placed on one XCD (blockIdx % 8 groups) so the planes are fetched
+//               from HBM once per chunk and re-read from that XCD's L2.
+//
+// References replaced: src/dft_solver.cu:294-307,346-380 (rho), :309-513 pass 2 + :541-548 (Vxc).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "xc_ws_kernels.hpp"
+
+namespace qcdft {
+
+constexpr int BG_THREADS = 512;
+constexpr int BG_BM = 128, BG_BN = 256, BG_BK = 16;
+constexpr int BG_LDA = BG_BK + 2;   // 18: A-operand reads conflict-free
+constexpr int BG_LDB = BG_BN + 16;  // 272 = 16 (mod 32)
+constexpr int BG_LDQ = BG_BM + 16;  // 144
+
+__device__ __forceinline__ double2 buf_load_d2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_double2(__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2]));
+}
+__device__ __forceinline__ double buf_load_d1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v[1], (int)v[0]);
+}
+// two consecutive doubles at byte offset voff+soff; VEC = 16-byte aligned rows (nao even)
+template <bool VEC>
+__device__ __forceinline__ double2 buf_load_pair2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    if (VEC) return buf_load_d2(r, voff, soff);
+    return make_double2(buf_load_d1(r, voff, soff), buf_load_d1(r, voff + 8, soff));
+}
+
+// ------------------------------------------------------------------ rho ----
+// Workgroup tile 128 rows x 128 columns of X (wave tile 64 x 32 = 4x2 MFMA tiles): the row-dot
+// epilogue needs ~100 VGPRs of its own, which a 4x4 wave tile (128 accumulator VGPRs) spills.
+constexpr int RB_BN = 128, RB_LDB = RB_BN + 16; // 144
+constexpr int RB_BK = 32, RB_LDA = RB_BK + 2;   // 34 = 2 (mod 32): 64 MFMAs per wave between barriers
+template <bool GRAD, bool VEC>
+__global__ __launch_bounds__(BG_THREADS, 2) void k_rho_big(long ngrid, int nao, int NP,
+                                                           const double *__restrict__ ao,
+                                                           const double *__restrict__ gx,
+                                                           const double *__restrict__ gy,
+                                                           const double *__restrict__ gz,
+                                                           const double *__restrict__ Dp,
+                                                           double *__restrict__ rho,
+                                                           double *__restrict__ grad,
+                                                           double *__restrict__ sigma)
+{
+    constexpr int ASZ = BG_BM * RB_LDA, BSZ = RB_BK * RB_LDB; // doubles per stage
+    __shared__ double lds[2 * (ASZ + BSZ)];                   // 143,360 B; the X slab aliases it
+    double *const As = lds, *const Bs = lds + 2 * ASZ;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3; // rows wm*64 + 16i (i<4), columns wn*32 + 16j (j<2)
+    const long g0 = (long)blockIdx.x * BG_BM;
+    const long plane = ngrid * (long)nao;
+    const int nkc = (NP + RB_BK - 1) / RB_BK;
+
+    // staging maps
+    const int a_row = tid >> 2, a_kq = tid & 3;   // A: 128 rows x 4 octets of k
+    const int b_row = tid >> 4, b_cq = tid & 15;  // B: 32 k-rows x 16 octets of n
+    const unsigned a_voff = (unsigned)(a_row * nao + 8 * a_kq) * 8u;
+    const __amdgpu_buffer_rsrc_t ra = plane_tile_rsrc(ao, plane, g0 * nao);
+    // epilogue map: 32 rows x 16 segs, columns 32q + 2seg + {0,1}, q < 4
+    const int e_row = tid >> 4, e_seg = tid & 15;
+
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, s3[4] = {0, 0, 0, 0};
+
+    for (int n0 = 0; n0 < NP; n0 += RB_BN) {
+        d4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+        double2 rav[4], rb[4];
+        auto fetch = [&](int kc) {
+            const unsigned soff = (unsigned)(kc * RB_BK) * 8u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rav[q] = buf_load_pair2<VEC>(ra, a_voff + 16 * q, soff);
+            const int k = kc * RB_BK + b_row, n = n0 + 8 * b_cq;
+            const bool ok = k < NP && n < NP; // NP is a multiple of 16: an octet is inside or outside
+            const double2 *src = reinterpret_cast<const double2 *>(Dp + (size_t)(ok ? k : 0) * NP + (ok ? n : 0));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double2 v = src[q];
+                rb[q] = ok ? v : make_double2(0.0, 0.0);
+            }
+        };
+        auto stash = [&](int buf) {
+            double *A = As + buf * ASZ + a_row * RB_LDA + 8 * a_kq;
+            double *B = Bs + buf * BSZ + b_row * RB_LDB + 8 * b_cq;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *reinterpret_cast<double2 *>(A + 2 * q) = rav[q];
+                *reinterpret_cast<double2 *>(B + 2 * q) = rb[q];
+            }
+        };
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (int kc = 0; kc < nkc; ++kc) {
+            const int buf = kc & 1;
+            if (kc + 1 < nkc) fetch(kc + 1);
+            const double *A = As + buf * ASZ + (wm * 64 + li) * RB_LDA + lk;
+            const double *B = Bs + buf * BSZ + lk * RB_LDB + wn * 32 + li;
+#pragma unroll
+            for (int ks = 0; ks < RB_BK / 4; ++ks) {
+                double af[4], bf[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = A[16 * i * RB_LDA + 4 * ks];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = B[4 * ks * RB_LDB + 16 * j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+            }
+            if (kc + 1 < nkc) stash(buf ^ 1);
+            __syncthreads();
+        }
+
+        // row dots of this 128 x 128 block of X, four 32-row slabs through LDS
+        double *Xs = lds; // 32 x RB_LDB doubles = 36,864 B
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (wm == (p >> 1)) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            Xs[(16 * ii + lk + 4 * r) * RB_LDB + wn * 32 + 16 * j + li] = acc[2 * (p & 1) + ii][j][r];
+            }
+            __syncthreads();
+            {
+                const long row0 = g0 + 32 * p;                 // slab's first grid row (wave-uniform)
+                const bool slab_ok = row0 < ngrid;              // uniform
+                const long e0 = (slab_ok ? row0 : 0) * (long)nao;
+                const unsigned voff = (unsigned)(e_row * nao + n0 + 2 * e_seg) * 8u;
+                const __amdgpu_buffer_rsrc_t r0 = plane_tile_rsrc(ao, plane, e0);
+                double2 v0[4], v1[4], v2[4], v3[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v0[q] = buf_load_pair2<VEC>(r0, voff, (unsigned)(32 * q) * 8u);
+                if (GRAD) {
+                    const __amdgpu_buffer_rsrc_t r1 = plane_tile_rsrc(gx, plane, e0);
+                    const __amdgpu_buffer_rsrc_t r2 = plane_tile_rsrc(gy, plane, e0);
+                    const __amdgpu_buffer_rsrc_t r3 = plane_tile_rsrc(gz, plane, e0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v1[q] = buf_load_pair2<VEC>(r1, voff, (unsigned)(32 * q) * 8u);
+                        v2[q] = buf_load_pair2<VEC>(r2, voff, (unsigned)(32 * q) * 8u);
+                        v3[q] = buf_load_pair2<VEC>(r3, voff, (unsigned)(32 * q) * 8u);
+                    }
+                }
+                double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double2 x = *reinterpret_cast<const double2 *>(&Xs[e_row * RB_LDB + 32 * q + 2 * e_seg]);
+                    t0 += x.x * v0[q].x + x.y * v0[q].y;
+                    if (GRAD) {
+                        t1 += x.x * v1[q].x + x.y * v1[q].y;
+                        t2 += x.x * v2[q].x + x.y * v2[q].y;
+                        t3 += x.x * v3[q].x + x.y * v3[q].y;
+                    }
+                }
+                if (slab_ok) { s0[p] += t0; s1[p] += t1; s2[p] += t2; s3[p] += t3; }
+            }
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const double t0 = row16_sum(s0[p]);
+        double t1 = 0, t2 = 0, t3 = 0;
+        if (GRAD) {
+            t1 = row16_sum(s1[p]);
+            t2 = row16_sum(s2[p]);
+            t3 = row16_sum(s3[p]);
+        }
+        const long g = g0 + 32 * p + e_row;
+        if (e_seg == 0 && g < ngrid) {
+            rho[g] = t0;
+            if (GRAD) {
+                const double ax = 2.0 * t1, ay = 2.0 * t2, az = 2.0 * t3;
+                grad[3 * g + 0] = ax;
+                grad[3 * g + 1] = ay;
+                grad[3 * g + 2] = az;
+                sigma[g] = ax * ax + ay * ay + az * az;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ Vxc ----
+// blockIdx.x -> (xcd = b % 8, slot = b / 8); pair = slot % npair; chunk = xcd + 8 * (slot / npair).
+// slabs: one nao x nao matrix per chunk; every (a-block, b-block) pair writes its own region.
+template <bool GRAD, bool VEC>
+__global__ __launch_bounds__(BG_THREADS, 2) void k_vxc_big(long ngrid, int nao, long chunk, int nB,
+                                                           int npair,
+                                                           const double *__restrict__ ao,
+                                                           const double *__restrict__ gx,
+                                                           const double *__restrict__ gy,
+                                                           const double *__restrict__ gz,
+                                                           const double *__restrict__ coef,
+                                                           double *__restrict__ slabs)
+{
+    constexpr int QSZ = BG_BK * BG_LDQ, PSZ = BG_BK * BG_LDB;
+    __shared__ double lds[2 * (QSZ + PSZ)]; // 106,496 B
+    double *const Qs = lds, *const Ps = lds + 2 * QSZ;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = slot % npair, ck = xcd + 8 * (slot / npair);
+    const int a0 = (pair / nB) * BG_BM, b0 = (pair % nB) * BG_BN;
+    const long glo = (long)ck * chunk, ghi = min(ngrid, glo + chunk);
+    const long plane = ngrid * (long)nao;
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    if (glo < ghi) {
+        const int nst = (int)((ghi - glo + BG_BK - 1) / BG_BK);
+        // staging maps: 16 rows x 32 column groups
+        const int s_row = tid >> 5, s_cq = tid & 31;
+        const unsigned q_voff = (unsigned)(s_row * nao + a0 + 4 * s_cq) * 8u; // 4 Q columns
+        const unsigned p_voff = (unsigned)(s_row * nao + b0 + 8 * s_cq) * 8u; // 8 P columns
+        const unsigned k_voff = (unsigned)s_row * 8u;
+        const double *c0 = coef, *c1 = coef + (size_t)ngrid, *c2 = coef + 2 * (size_t)ngrid,
+                     *c3 = coef + 3 * (size_t)ngrid;
+
+        double2 q0[2], q1[2], q2[2], q3[2], pp[4];
+        double k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+        auto fetch = [&](int st) {
+            const long row0 = glo + (long)st * BG_BK; // < ghi <= ngrid
+            const long e0 = row0 * nao;
+            // the chunk ends at ghi: rows >= ghi must not contribute -> descriptor ends at ghi
+            const long pend = ghi * (long)nao;
+            const __amdgpu_buffer_rsrc_t r0 = plane_tile_rsrc(ao, pend, e0);
+            k0 = buf_load_d1(plane_tile_rsrc(c0, ghi, row0), k_voff, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) q0[h] = buf_load_pair2<VEC>(r0, q_voff + 16 * h, 0);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) pp[h] = buf_load_pair2<VEC>(r0, p_voff + 16 * h, 0);
+            if (GRAD) {
+                const __amdgpu_buffer_rsrc_t r1 = plane_tile_rsrc(gx, pend, e0);
+                const __amdgpu_buffer_rsrc_t r2 = plane_tile_rsrc(gy, pend, e0);
+                const __amdgpu_buffer_rsrc_t r3 = plane_tile_rsrc(gz, pend, e0);
+                k1 = buf_load_d1(plane_tile_rsrc(c1, ghi, row0), k_voff, 0);
+                k2 = buf_load_d1(plane_tile_rsrc(c2, ghi, row0), k_voff, 0);
+                k3 = buf_load_d1(plane_tile_rsrc(c3, ghi, row0), k_voff, 0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    q1[h] = buf_load_pair2<VEC>(r1, q_voff + 16 * h, 0);
+                    q2[h] = buf_load_pair2<VEC>(r2, q_voff + 16 * h, 0);
+                    q3[h] = buf_load_pair2<VEC>(r3, q_voff + 16 * h, 0);
+                }
+            }
+        };
+        auto stash = [&](int buf) {
+            double *Q = Qs + buf * QSZ + s_row * BG_LDQ + 4 * s_cq;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double qa = k0 * q0[h].x, qb = k0 * q0[h].y;
+                if (GRAD) {
+                    qa += k1 * q1[h].x + k2 * q2[h].x + k3 * q3[h].x;
+                    qb += k1 * q1[h].y + k2 * q2[h].y + k3 * q3[h].y;
+                }
+                *reinterpret_cast<double2 *>(Q + 2 * h) = make_double2(qa, qb);
+            }
+            double *P = Ps + buf * PSZ + s_row * BG_LDB + 8 * s_cq;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) *reinterpret_cast<double2 *>(P + 2 * h) = pp[h];
+        };
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nst) fetch(st + 1);
+            const double *Q = Qs + buf * QSZ + lk * BG_LDQ + wm * 64 + li;
+            const double *P = Ps + buf * PSZ + lk * BG_LDB + wn * 64 + li;
+#pragma unroll
+            for (int ks = 0; ks < BG_BK / 4; ++ks) {
+                double af[4], bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = Q[4 * ks * BG_LDQ + 16 * i];
+                    bf[i] = P[4 * ks * BG_LDB + 16 * i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+            }
+            if (st + 1 < nst) stash(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    double *slab = slabs + (size_t)ck * nao * nao;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = b0 + wn * 64 + 16 * j + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = a0 + wm * 64 + 16 * i + lk + 4 * r;
+                if (a < nao && b < nao) slab[(size_t)a * nao + b] = acc[i][j][r];
+            }
+        }
+}
+
+} // namespace qcdft

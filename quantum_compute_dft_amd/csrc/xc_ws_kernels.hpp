@@ -490,25 +490,43 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
     }
 }
 
-// V = sum of the per-workgroup slabs in a fixed order (bitwise reproducible): 32 elements x 8
-// slab groups per block, then a fixed tree over the groups.  SYM adds the transpose (M + M^T,
-// what symmetrize_matrix_kernel does for B3LYP, src/dft_solver.cu:515-527).
-// The block that FINISHES LAST (device-scope ticket after its V stores are fenced) completes
-// Exc: fixed-order sum of the per-block partials of k_xc_points (reduce_sum_kernel,
-// src/dft_solver.cu:285-292, made deterministic), stored to the device scalar and, if given,
-// to host-mapped memory.  Because that store is ordered after every V store of the launch,
-// the host may return from DFT_ComputeXC as soon as it sees the value (no copy launch, no
-// sleeping synchronise).
-template <bool SYM> // SYM only for slabs of the generic path (the wave-specialised kernel pre-symmetrises)
-__global__ __launch_bounds__(256) void k_reduce_slabs8(int nao, int nslab,
-                                                       const double *__restrict__ slabs,
-                                                       double *__restrict__ V, long npart,
-                                                       const double *__restrict__ partial,
-                                                       double *__restrict__ exc_dev,
-                                                       double *exc_host, unsigned *ticket)
+// Last launch of every DFT_ComputeXC call (one block): fixed-order sum of the per-block partials
+// of k_xc_points (reduce_sum_kernel, src/dft_solver.cu:285-292, made deterministic), stored to the
+// device scalar and, if given, to host-mapped memory.  Stream order puts it after every Vxc store
+// of the call, so the host may return as soon as it sees the value (no copy launch, no sleeping
+// synchronise).  (A last-block ticket inside the reduce kernel was tried first: its per-block
+// __threadfence() cost 10-30 us.)
+__global__ __launch_bounds__(256) void k_finish_exc(long npart, const double *__restrict__ partial,
+                                                    double *__restrict__ exc_dev, double *exc_host)
 {
     __shared__ double part[256];
-    __shared__ bool last;
+    double x = 0.0;
+    for (long i = threadIdx.x; i < npart; i += 256) x += partial[i];
+    part[threadIdx.x] = x;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) part[threadIdx.x] += part[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        exc_dev[0] = part[0];
+        if (exc_host) {
+            *(volatile double *)exc_host = part[0];
+            __threadfence_system();
+        }
+    }
+}
+
+// V = sum of the per-workgroup slabs in a fixed order (bitwise reproducible): 32 elements x 8
+// slab groups per block, then a fixed tree over the groups.  SYM adds the transpose with
+// transposed reads (validation path only; the production paths symmetrise in-kernel or with
+// k_symmetrize).
+template <bool SYM>
+__global__ __launch_bounds__(256) void k_reduce_slabs8(int nao, int nslab,
+                                                       const double *__restrict__ slabs,
+                                                       double *__restrict__ V)
+{
+    __shared__ double part[256];
     const size_t n2 = (size_t)nao * nao;
     const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const size_t e = (size_t)blockIdx.x * 32 + el;
@@ -528,27 +546,32 @@ __global__ __launch_bounds__(256) void k_reduce_slabs8(int nao, int nslab,
     if (grp == 0 && e < n2) {
         const double *p = &part[el];
         V[e] = ((p[0] + p[32]) + (p[64] + p[96])) + ((p[128] + p[160]) + (p[192] + p[224]));
-        __threadfence(); // this block's V stores are visible device-wide before its ticket
+    }
+}
+
+// V = M + M^T (B3LYP, symmetrize_matrix_kernel src/dft_solver.cu:515-527) for the nao > 128 path:
+// 32x32 tiles through LDS, block (ti <= tj) owns the tile pair, coalesced on both sides.
+__global__ __launch_bounds__(256) void k_symmetrize(int nao, const double *__restrict__ M,
+                                                    double *__restrict__ V)
+{
+    __shared__ double A[32][33], B[32][33];
+    const int nt = (nao + 31) / 32;
+    int ti = 0, rem = blockIdx.x; // linear block index -> (ti <= tj)
+    while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
+    const int tj = ti + rem;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int a = 32 * ti + r, b = 32 * tj + tx;
+        A[r][tx] = (a < nao && b < nao) ? M[(size_t)a * nao + b] : 0.0;
+        const int a2 = 32 * tj + r, b2 = 32 * ti + tx;
+        B[r][tx] = (a2 < nao && b2 < nao) ? M[(size_t)a2 * nao + b2] : 0.0;
     }
     __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!last) return;
-    double x = 0.0;
-    for (long i = threadIdx.x; i < npart; i += 256) x += partial[i];
-    part[threadIdx.x] = x;
-    __syncthreads();
-    for (int m = 128; m >= 1; m >>= 1) {
-        if ((int)threadIdx.x < m) part[threadIdx.x] += part[threadIdx.x + m];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        *ticket = 0; // ready for the next call on this stream
-        exc_dev[0] = part[0];
-        if (exc_host) {
-            *(volatile double *)exc_host = part[0];
-            __threadfence_system();
-        }
+    for (int r = ty; r < 32; r += 8) {
+        const int a = 32 * ti + r, b = 32 * tj + tx;
+        if (a < nao && b < nao) V[(size_t)a * nao + b] = A[r][tx] + B[tx][r];
+        const int a2 = 32 * tj + r, b2 = 32 * ti + tx;
+        if (ti != tj && a2 < nao && b2 < nao) V[(size_t)a2 * nao + b2] = A[tx][r] + B[r][tx]; // same two addends: bitwise symmetric
     }
 }
 

@@ -79,7 +79,8 @@ def test_appendix_d_golden_through_the_abi(dev, golden_dir, xc_type):
 
 # (ngrid, nao): ragged sizes around the tile edges (16/32/64/128) and both paths
 SHAPES = [(1, 1), (7, 3), (96, 5), (257, 13), (1000, 16), (1025, 17), (4097, 24), (3001, 36),
-          (2000, 64), (1531, 65), (2500, 114), (1300, 128), (700, 129), (900, 200)]
+          (2000, 64), (1531, 65), (2500, 114), (1300, 128), (700, 129), (900, 200), (1111, 246),
+          (300, 257), (2100, 301), (130, 494)]
 
 
 @pytest.mark.parametrize("ngrid,nao", SHAPES)
@@ -94,7 +95,7 @@ def test_sweep_matches_oracle(dev, xc_type, ngrid, nao):
 @pytest.mark.parametrize("path", [1, 2])   # 1 = plain-VALU validation kernels, 2 = generic MFMA kernels
 @pytest.mark.parametrize("xc_type", [0, 1, 2])
 def test_alternative_kernel_paths_match_oracle(dev, xc_type, path):
-    for ngrid, nao in ((777, 37), (1500, 114)):
+    for ngrid, nao in ((777, 37), (1500, 114), (600, 150)):
         dm, ao, gr, w = synth_inputs(ngrid, nao, seed=5)
         exc_ref, v_ref = oracle.compute_xc(xc_type, dm, ao, w, gr)
         exc, v = _run(_solver(xc_type, path=path), dm, ao, gr if xc_type else None, w, dev)
