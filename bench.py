@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--workload", default="benzene_gga_def2svp", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo only to rehearse N>1 on a single card")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,17 +144,25 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    dev_index = local if args.backend == "nccl" else local % max(1, ndev)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     xc, nao, ngrid = WORKLOADS[args.workload]
     dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)   # dm identical on all ranks
     if world > 1:
-        dist.broadcast(dm, 0)
+        if args.backend == "nccl":
+            dist.broadcast(dm, 0)
+        else:
+            h = dm.cpu(); dist.broadcast(h, 0); dm.copy_(h)
     solver = q.DFTSolverWrapper(q.build_library(), xc)
     out = torch.zeros(nao * nao + 1, dtype=torch.float64, device=dev)   # [Vxc | Exc]
     d_v, d_e = out[: nao * nao], out[nao * nao:]
@@ -161,7 +171,10 @@ def main():
         if world == 1:
             return solver.compute_xc(ngrid, nao, dm, ao, w, d_v, gr)    # synchronous, returns Exc
         solver.compute_xc_async(ngrid, nao, dm, ao, w, d_v, d_e, gr)
-        dist.all_reduce(out)                                            # sum of the shard partials
+        if args.backend == "nccl":
+            dist.all_reduce(out)                                        # sum of the shard partials
+        else:                                                           # rehearsal: gloo reduces on the host
+            h = out.cpu(); dist.all_reduce(h); out.copy_(h)
         return float(d_e.item())                                        # device sync, like the ABI call
 
     def fence():
@@ -178,7 +191,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
