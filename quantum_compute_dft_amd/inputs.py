@@ -1,0 +1,53 @@
+"""Input builder: counterpart of the reference's grid.py (`build`, `get_ao_grad`, grid.py:23-67)
+without PySCF: molecule + basis -> shell table, level-3 Becke/Lebedev grid, S, T, V, dense ERI,
+E_nuc, electron count.  AO values / gradients are NOT built here: the driver evaluates them on the
+device with DFT_EvalAO (grid.py:30,38 did it on the CPU and dft.py:155,172 uploaded them)."""
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import basis, grid_gen, integrals
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+@dataclass
+class SCFInputs:
+    symbols: list
+    atom_xyz: np.ndarray   # bohr
+    shells: basis.ShellTable
+    grids: grid_gen.Grids
+    S: np.ndarray
+    T: np.ndarray
+    V: np.ndarray
+    Hcore: np.ndarray
+    eri: np.ndarray        # (nao, nao, nao, nao)
+    E_nuc: float
+    nocc: int
+    nelec: int
+
+
+def build(atom_path, basis_name="sto-3g", grid_level=3, device="cpu", verbose=True):
+    """grid.py:42-67.  `atom_path`: an .xyz file (or a molecule name resolved in data/)."""
+    if not os.path.exists(atom_path):
+        cand = os.path.join(DATA_DIR, atom_path if atom_path.endswith(".xyz") else atom_path + ".xyz")
+        if os.path.exists(cand):
+            atom_path = cand
+    symbols, xyz = basis.parse_xyz(atom_path)
+    shells = basis.build_shells(symbols, xyz, basis_name)
+    nelec = sum(basis.atomic_number(s) for s in symbols)
+    if nelec % 2:
+        raise ValueError("closed-shell (RKS) only: odd electron count")
+    nocc = nelec // 2
+    if verbose:  # grid.py:54-56,60
+        print(f"Number of basis functions: {shells.nao}")
+        print(f"Number of electrons: {nelec}")
+        print(f"Number of occupied orbitals: {nocc}")
+    grids = grid_gen.Grids(symbols, xyz, level=grid_level, device=device)
+    if verbose:
+        print(f"Number of grid points for integration: {grids.size}")
+    S, T, V = integrals.int1e(shells, symbols, xyz)
+    eri = integrals.int2e(shells)
+    return SCFInputs(symbols, xyz, shells, grids, S, T, V, T + V, eri,
+                     integrals.energy_nuc(symbols, xyz), nocc, nelec)

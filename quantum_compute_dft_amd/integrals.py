@@ -1,0 +1,85 @@
+"""S, T, V, dense ERI and E_nuc for the SCF driver -- host-side counterpart of the PySCF calls at
+grid.py:61-66 (`mol.intor('int1e_ovlp'|'int1e_kin'|'int1e_nuc'|'int2e')`, `mol.energy_nuc()`).
+The arithmetic is csrc/integrals.c (McMurchie-Davidson, OpenMP), built in-tree with gcc.
+
+PARITY UNPINNED against PySCF/libcint (not installed); pinned offline by quadrature on the
+Becke grid, textbook H2/STO-3G integrals and RHF energies (tests/test_integrals.py)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from .basis import atomic_number
+from .build import CSRC, LIB_DIR
+
+_LIB_PATH = os.path.join(LIB_DIR, "libqcint.so")
+_SRC = os.path.join(CSRC, "integrals.c")
+_lib = None
+
+
+def build_integrals(force=False):
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_SRC) > os.path.getmtime(_LIB_PATH):
+        os.makedirs(LIB_DIR, exist_ok=True)
+        subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-fopenmp", "-std=c11", _SRC, "-o", _LIB_PATH, "-lm"],
+                       check=True)
+    return _LIB_PATH
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build_integrals())
+        dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+        L.qc_int1e.restype = ctypes.c_int
+        L.qc_int1e.argtypes = [ctypes.c_int, dp, ip, ip, ip, ip, dp, dp, ctypes.c_int, ctypes.c_int, dp, dp, dp, dp, dp]
+        L.qc_int2e.restype = ctypes.c_int
+        L.qc_int2e.argtypes = [ctypes.c_int, dp, ip, ip, ip, ip, dp, dp, ctypes.c_int, dp]
+        _lib = L
+    return _lib
+
+
+def _args(sh):
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+    keep = [np.ascontiguousarray(sh.xyz, dtype=np.float64), np.ascontiguousarray(sh.l, dtype=np.int32),
+            np.ascontiguousarray(sh.nprim, dtype=np.int32), np.ascontiguousarray(sh.off, dtype=np.int32),
+            np.ascontiguousarray(sh.ao, dtype=np.int32), np.ascontiguousarray(sh.exp, dtype=np.float64),
+            np.ascontiguousarray(sh.coef, dtype=np.float64)]
+    ptrs = [keep[0].ctypes.data_as(dp)] + [k.ctypes.data_as(ip) for k in keep[1:5]] + [k.ctypes.data_as(dp) for k in keep[5:]]
+    return keep, ptrs
+
+
+def int1e(shells, symbols, atom_xyz):
+    """(S, T, V) as (nao, nao) arrays; V is the nuclear-attraction matrix (negative)."""
+    keep, p = _args(shells)
+    n = shells.nao
+    S, T, V = np.zeros((n, n)), np.zeros((n, n)), np.zeros((n, n))
+    axyz = np.ascontiguousarray(atom_xyz, dtype=np.float64)
+    z = np.array([atomic_number(s) for s in symbols], dtype=np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = _load().qc_int1e(shells.nshell, *p, n, len(z), axyz.ctypes.data_as(dp), z.ctypes.data_as(dp),
+                          S.ctypes.data_as(dp), T.ctypes.data_as(dp), V.ctypes.data_as(dp))
+    if rc != 0:
+        raise ValueError("integrals: angular momentum above f is not supported")
+    return S, T, V
+
+
+def int2e(shells):
+    """Dense (nao, nao, nao, nao) electron-repulsion tensor, chemists' notation (ij|kl)."""
+    keep, p = _args(shells)
+    n = shells.nao
+    eri = np.zeros((n, n, n, n))
+    rc = _load().qc_int2e(shells.nshell, *p, n, eri.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    if rc != 0:
+        raise ValueError("integrals: angular momentum above f is not supported")
+    return eri
+
+
+def energy_nuc(symbols, atom_xyz):
+    z = np.array([atomic_number(s) for s in symbols], dtype=np.float64)
+    xyz = np.asarray(atom_xyz, dtype=np.float64)
+    e = 0.0
+    for i in range(len(z)):
+        for j in range(i):
+            e += z[i] * z[j] / np.linalg.norm(xyz[i] - xyz[j])
+    return e

@@ -1,0 +1,89 @@
+"""Offline pins of the integral engine (PySCF/libcint itself is not available)."""
+import os
+
+import numpy as np
+import pytest
+from scipy.linalg import eigh
+
+import oracle
+from quantum_compute_dft_amd import basis, grid_gen, integrals
+
+DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "quantum_compute_dft_amd", "data")
+
+
+def _rhf(S, H, eri, nocc, enuc, iters=60):
+    e, C = eigh(H, S)
+    dm = 2 * C[:, :nocc] @ C[:, :nocc].T
+    E = 0
+    for _ in range(iters):
+        J = np.einsum("ijkl,kl->ij", eri, dm); K = np.einsum("ikjl,kl->ij", eri, dm)
+        F = H + J - 0.5 * K
+        E = 0.5 * np.sum(dm * (H + F)) + enuc
+        e, C = eigh(F, S)
+        dm = 2 * C[:, :nocc] @ C[:, :nocc].T
+    return E
+
+
+def test_h2_sto3g_textbook_values():
+    # Szabo & Ostlund, R = 1.4 bohr: S12 0.6593, T11 0.7600, (11|11) 0.7746, (11|22) 0.5697,
+    # (21|11) 0.4441, (21|21) 0.2970, E(RHF) -1.1167
+    syms, xyz = ["H", "H"], np.array([[0, 0, 0], [0, 0, 1.4]])
+    sh = basis.build_shells(syms, xyz, "sto-3g")
+    S, T, V = integrals.int1e(sh, syms, xyz)
+    eri = integrals.int2e(sh)
+    assert S[0, 1] == pytest.approx(0.6593, abs=1e-4) and S[0, 0] == pytest.approx(1.0, abs=1e-12)
+    assert T[0, 0] == pytest.approx(0.7600, abs=1e-4) and T[0, 1] == pytest.approx(0.2365, abs=1e-4)
+    assert V[0, 0] == pytest.approx(-1.2266 - 0.6538, abs=2e-4)
+    assert eri[0, 0, 0, 0] == pytest.approx(0.7746, abs=1e-4)
+    assert eri[0, 0, 1, 1] == pytest.approx(0.5697, abs=1e-4)
+    assert eri[1, 0, 0, 0] == pytest.approx(0.4441, abs=1e-4)
+    assert eri[1, 0, 1, 0] == pytest.approx(0.2970, abs=1e-4)
+    E = _rhf(S, T + V, eri, 1, integrals.energy_nuc(syms, xyz))
+    assert E == pytest.approx(-1.1167, abs=1e-4)
+
+
+@pytest.mark.parametrize("bname", ["sto-3g", "def2-svp"])
+def test_one_electron_integrals_against_quadrature(bname):
+    syms, xyz = basis.parse_xyz(os.path.join(DATA, "H2O.xyz"))
+    sh = basis.build_shells(syms, xyz, bname)
+    g = grid_gen.Grids(syms, xyz, level=3)
+    ao, gr = oracle.eval_ao(sh, g.coords, deriv=1)
+    S, T, V = integrals.int1e(sh, syms, xyz)
+    w = g.weights
+    Sq = ao.T @ (w[:, None] * ao)
+    Tq = 0.5 * sum(gr[c].T @ (w[:, None] * gr[c]) for c in range(3))
+    assert np.abs(S - Sq).max() < 3e-5 and np.allclose(S, S.T, atol=1e-13)
+    assert np.abs(T - Tq).max() < 2e-3 and np.allclose(T, T.T, atol=1e-12)   # core functions: quadrature-limited
+    vpot = -sum(basis.atomic_number(s) / np.linalg.norm(g.coords - R, axis=1) for s, R in zip(syms, xyz))
+    Vq = ao.T @ ((w * vpot)[:, None] * ao)
+    assert np.abs(V - Vq).max() < 5e-3 * max(1.0, np.abs(V).max() / 10) and np.allclose(V, V.T, atol=1e-11)
+
+
+def test_eri_symmetry_and_tight_gaussian_limit():
+    # (ij|kk) with k a very tight normalised s function at R -> sqrt(<k|k>-weighted) point charge:
+    # (ij|kk) -> -V_ij of a unit charge at R (k*k integrates to 1 for an s product? use its density norm)
+    syms, xyz = basis.parse_xyz("O 0 0 0.1173; H 0 0.7572 -0.4692; H 0 -0.7572 -0.4692")
+    tight = 4.0e6
+    basis.register_basis("probe", {"O": basis._DEF2_SVP["O"], "H": basis._DEF2_SVP["H"], "He": [(0, [(tight, 1.0)])]})
+    R = np.array([[0.3, -0.2, 0.5]])
+    syms2, xyz2 = syms + ["He"], np.vstack([xyz, R])
+    sh = basis.build_shells(syms2, xyz2, "probe")
+    eri = integrals.int2e(sh)
+    n = sh.nao
+    for perm in ((1, 0, 2, 3), (0, 1, 3, 2), (2, 3, 0, 1), (3, 2, 1, 0)):
+        assert np.allclose(eri, eri.transpose(perm), atol=1e-12)
+    k = n - 1                                        # the probe function
+    S, T, V = integrals.int1e(sh, ["He"], R)         # attraction to a unit... Z=2 charge at R
+    skk = S[k, k]
+    # density phi_k^2 integrates to 1 (normalised) and is a delta function on this scale
+    assert np.allclose(eri[:n - 1, :n - 1, k, k], -V[:n - 1, :n - 1] / 2.0 * skk, rtol=2e-4, atol=2e-6)
+
+
+def test_water_sto3g_rhf_energy_is_sane():
+    # RHF/STO-3G water at the reference's H2O.xyz geometry: literature values for near-equilibrium
+    # geometries are -74.96 +- 0.01 Ha
+    syms, xyz = basis.parse_xyz(os.path.join(DATA, "H2O.xyz"))
+    sh = basis.build_shells(syms, xyz, "sto-3g")
+    S, T, V = integrals.int1e(sh, syms, xyz)
+    E = _rhf(S, T + V, integrals.int2e(sh), 5, integrals.energy_nuc(syms, xyz))
+    assert -74.98 < E < -74.94

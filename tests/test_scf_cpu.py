@@ -1,0 +1,37 @@
+"""The SCF loop (dft.py:181-266 contract) on the CPU oracle backend: plumbing of inputs -> loop."""
+import numpy as np
+import pytest
+
+from quantum_compute_dft_amd import inputs, scf
+from scf_oracle_backend import OracleBackend
+
+
+@pytest.fixture(scope="module")
+def water():
+    return inputs.build("H2O", "sto-3g", 3, verbose=False)
+
+
+def test_inputs_are_consistent(water):
+    assert water.shells.nao == 7 and water.grids.size == 34310 and water.nocc == 5
+    assert np.allclose(water.S, water.S.T) and np.allclose(np.diag(water.S), 1.0, atol=1e-12)
+    e = water.eri
+    assert np.allclose(e, e.transpose(2, 3, 0, 1), atol=1e-12)
+
+
+@pytest.mark.parametrize("fn,lo,hi", [("LDA", -74.80, -74.68), ("GGA", -75.30, -75.17), ("B3LYP", -75.39, -75.25)])
+def test_scf_converges_and_counts_electrons(water, fn, lo, hi):
+    be = OracleBackend(water, fn, quirks=False)
+    r = scf.run_scf(water, be, fn, log=None)
+    assert r["converged"] and r["cycles"] < 30
+    assert lo < r["E_tot"] < hi                      # literature range for water / STO-3G
+    rho = np.einsum("gi,ij,gj->g", be.ao, r["dm"], be.ao)
+    assert float(water.grids.weights @ rho) == pytest.approx(10.0, abs=2e-4)   # integral of rho = N_elec
+    assert np.trace(r["dm"] @ water.S) == pytest.approx(10.0, abs=1e-9)
+
+
+def test_reference_derivative_quirks_shift_converged_energies(water):
+    # measured: 4e-8 Ha (LDA, VWN5 dec_dx) and 4.5e-6 Ha (GGA, PBE-c dx_drho) on water/STO-3G
+    for fn, lo, hi in (("LDA", 1e-9, 1e-5), ("GGA", 1e-7, 1e-4)):
+        a = scf.run_scf(water, OracleBackend(water, fn, quirks=True), fn, log=None, conv_e=1e-11, conv_dm=1e-9)["E_tot"]
+        b = scf.run_scf(water, OracleBackend(water, fn, quirks=False), fn, log=None, conv_e=1e-11, conv_dm=1e-9)["E_tot"]
+        assert lo < abs(a - b) < hi, (fn, a - b)
