@@ -112,6 +112,45 @@ def cpu_baseline(xc, dm, ao, gr, w, target_seconds):
                       f"{threads} threads"}
 
 
+def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=5):
+    """One SCF iteration as dft.py:199-236 does it, on the same synthetic shapes: H2D dm, J (+K for
+    B3LYP, one pass over a synthetic dense ERI), XC sweep, D2H, host DIIS-free Fock build + eigh.
+    Skipped when the dense ERI does not fit comfortably (nao > 200)."""
+    if nao > 200:
+        return None
+    from scipy.linalg import eigh
+    n2 = nao * nao
+    eri = torch.randn((n2, n2), dtype=torch.float64, device=dev) * 1e-3
+    S = np.eye(nao); H = np.diag(np.linspace(-1.0, 1.0, nao))
+    d_J = torch.zeros((nao, nao), dtype=torch.float64, device=dev); d_K = torch.zeros_like(d_J)
+    d_v = torch.zeros_like(d_J); d_dm = dm.clone()
+    dm_h = dm.cpu().numpy()
+    nocc = max(1, nao // 5)
+    parts = {"h2d": 0.0, "jk": 0.0, "xc": 0.0, "d2h": 0.0, "host_eigh": 0.0}
+    t_all = 0.0
+    for it in range(iters + 1):
+        t0 = time.perf_counter()
+        d_dm.copy_(torch.as_tensor(dm_h)); torch.cuda.synchronize(); t1 = time.perf_counter()
+        if xc == "B3LYP":
+            solver.compute_jk(nao, eri, d_dm, d_J, d_K)
+        else:
+            solver.compute_coulomb(nao, eri, d_dm, d_J)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        solver.compute_xc(ngrid, nao, d_dm, ao, w, d_v, gr); t3 = time.perf_counter()
+        J = d_J.cpu().numpy(); V = d_v.cpu().numpy(); K = d_K.cpu().numpy() if xc == "B3LYP" else 0.0
+        t4 = time.perf_counter()
+        F = H + 1e-3 * (J + 0.5 * (V + V.T) - 0.1 * K)
+        e, C = eigh(F, S); dm_new = 2.0 * C[:, :nocc] @ C[:, :nocc].T
+        t5 = time.perf_counter()
+        if it:  # first iteration warms allocations
+            for k, a, b in (("h2d", t0, t1), ("jk", t1, t2), ("xc", t2, t3), ("d2h", t3, t4), ("host_eigh", t4, t5)):
+                parts[k] += (b - a) * 1e3 / iters
+            t_all += (t5 - t0) * 1e3 / iters
+    del eri
+    return {"ms": t_all, "parts_ms": parts, "eri_bytes": 8.0 * n2 * n2,
+            "note": "synthetic dm/ERI; J" + ("+K one pass" if xc == "B3LYP" else "") + ", XC, host eigh (scipy) as in dft.py:199-236"}
+
+
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled
     per the gfx950 correction, + WRITE_SIZE); None when no profile matches this workload."""
@@ -238,6 +277,10 @@ def main():
                       "mfma_frac_of_step": f_all / (dt / args.steps) / 1e12 / F64_MFMA_PEAK_TF},
             "kernels_ms": kern, "exc": exc,
         }
+        if world == 1:
+            si = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev)
+            if si:
+                line["scf_iteration"] = si
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(xc, dm, ao, gr, w, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -61,11 +61,14 @@ template <int NT> struct WsCfg {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// `live` = false gives a ZERO-record descriptor: every load through it is dropped by the range
+// check (returns 0, no memory traffic) yet still counts in vmcnt -- used for the pipeline-drain
+// steps, so the loader loop stays branch-free without re-reading a tile.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_tile_rsrc(const double *plane, long plane_elems,
-                                                                  long first_elem)
+                                                                  long first_elem, bool live = true)
 {
     const long remain = (plane_elems - first_elem) * 8; // bytes to the end of the plane (> 0)
-    const unsigned nrec = remain > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)remain;
+    const unsigned nrec = !live ? 0u : remain > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)remain;
     return __builtin_amdgcn_make_buffer_rsrc((void *)(plane + first_elem), 0, nrec, 0x00020000);
 }
 // pair (c, c+1) of one row: `voff` = byte offset of (row, 2*seg) in the tile, IMM = 256*j
@@ -155,33 +158,43 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_vxc_ws(long ngrid, int nao,
 #ifdef QCDFT_STAMPS
         unsigned long long st_acc[4] = {0, 0, 0, 0};
 #endif
+        // Operand fragments are software-pipelined one k-step ahead, ACROSS the step barrier: the
+        // slot consumed at step s+1 was published by the barrier of step s-1 (ring latency 2), so
+        // its first fragments are fetched before this step's barrier and the MFMA pipe restarts
+        // without an LDS round trip (the barrier only hands slots back to the loaders).
+        const int fo = lk * C::LDX + li;
+        double af[NTW], bf[NTW];
+        auto load_frags = [&](int slot, int ks, double (&a_)[NTW], double (&b_)[NTW]) {
+            const double *P = Ps + slot * TILE + fo + 4 * ks * C::LDX;
+            const double *Q = Qs + slot * TILE + fo + 4 * ks * C::LDX;
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                a_[i] = Q[16 * min(wa + 2 * i, NT - 1)]; // clamped: unowned tiles skipped below
+                b_[i] = P[16 * min(wb + 2 * i, NT - 1)];
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) { af[i] = 0.0; bf[i] = 0.0; }
         for (long base = 0; base < nstep; base += WS_RING) {
 #pragma unroll
             for (int u = 0; u < WS_RING; ++u) {
                 const long step = base + u;
                 QCDFT_T(ta);
-#if defined(QCDFT_EXP) && QCDFT_EXP == 1
-                if (false) {
-#else
                 if (step >= 2 && step < nstep) { // consume sub-tile step-2 from stage (u+2)%4
-#endif
-                    const double *P = Ps + ((u + 2) % WS_RING) * TILE;
-                    const double *Q = Qs + ((u + 2) % WS_RING) * TILE;
+                    if (step == 2) load_frags((u + 2) % WS_RING, 0, af, bf); // first consumed sub-tile
 #pragma unroll
                     for (int ks = 0; ks < WS_ROWS / 4; ++ks) {
-                        const int o = (4 * ks + lk) * C::LDX + li;
-                        double af[NTW], bf[NTW];
-#pragma unroll
-                        for (int i = 0; i < NTW; ++i) {
-                            af[i] = Q[o + 16 * min(wa + 2 * i, NT - 1)]; // clamped: unowned tiles skipped below
-                            bf[i] = P[o + 16 * min(wb + 2 * i, NT - 1)];
-                        }
+                        double an[NTW], bn[NTW];
+                        if (ks + 1 < WS_ROWS / 4) load_frags((u + 2) % WS_RING, ks + 1, an, bn);
+                        else                      load_frags((u + 3) % WS_RING, 0, an, bn); // next step's slot (may be unused garbage at the tail)
 #pragma unroll
                         for (int i = 0; i < NTW; ++i)
 #pragma unroll
                             for (int j = 0; j < NTW; ++j)
                                 if ((2 * i + 1 < NT || i < na) && (2 * j + 1 < NT || j < nb))
                                     acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+#pragma unroll
+                        for (int i = 0; i < NTW; ++i) { af[i] = an[i]; bf[i] = bn[i]; }
                     }
                 }
                 QCDFT_T(tb);
@@ -244,19 +257,20 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_vxc_ws(long ngrid, int nao,
         const long plane = ngrid * (long)nao;
         const unsigned voff = (unsigned)(row * nao + 2 * seg) * 8u, koff = (unsigned)row * 8u;
         auto issue = [&](int set, long s) {
+            const bool live = s < nloc;                                               // drain steps load nothing
             const long row0 = (blockIdx.x + min(s, nloc - 1) * gridDim.x) * WS_ROWS; // wave-uniform
             const long e0 = row0 * nao;
-            k0[set] = buf_load_f64(plane_tile_rsrc(c0, ngrid, row0), koff);
+            k0[set] = buf_load_f64(plane_tile_rsrc(c0, ngrid, row0, live), koff);
             if (GRAD) {
-                k1[set] = buf_load_f64(plane_tile_rsrc(c1, ngrid, row0), koff);
-                k2[set] = buf_load_f64(plane_tile_rsrc(c2, ngrid, row0), koff);
-                k3[set] = buf_load_f64(plane_tile_rsrc(c3, ngrid, row0), koff);
+                k1[set] = buf_load_f64(plane_tile_rsrc(c1, ngrid, row0, live), koff);
+                k2[set] = buf_load_f64(plane_tile_rsrc(c2, ngrid, row0, live), koff);
+                k3[set] = buf_load_f64(plane_tile_rsrc(c3, ngrid, row0, live), koff);
             }
-            buf_load_row<C::JN, VEC>(plane_tile_rsrc(ao, plane, e0), voff, p0[set]);
+            buf_load_row<C::JN, VEC>(plane_tile_rsrc(ao, plane, e0, live), voff, p0[set]);
             if (GRAD) {
-                buf_load_row<C::JN, VEC>(plane_tile_rsrc(gx, plane, e0), voff, p1[set]);
-                buf_load_row<C::JN, VEC>(plane_tile_rsrc(gy, plane, e0), voff, p2[set]);
-                buf_load_row<C::JN, VEC>(plane_tile_rsrc(gz, plane, e0), voff, p3[set]);
+                buf_load_row<C::JN, VEC>(plane_tile_rsrc(gx, plane, e0, live), voff, p1[set]);
+                buf_load_row<C::JN, VEC>(plane_tile_rsrc(gy, plane, e0, live), voff, p2[set]);
+                buf_load_row<C::JN, VEC>(plane_tile_rsrc(gz, plane, e0, live), voff, p3[set]);
             }
         };
         issue(0, 0);
@@ -275,9 +289,6 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_vxc_ws(long ngrid, int nao,
                 asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); // the 20 loads of the newer set may stay in flight
 #endif
                 QCDFT_T(tw);
-#if defined(QCDFT_EXP) && QCDFT_EXP == 2
-                if (step < 2)
-#endif
                 { // stage sub-tile `step` into ring slot u (steps >= nloc stage rows that are never read;
                   // rows past the grid arrive as zeros from the range-checked loads)
                     double *P = Ps + u * TILE, *Q = Qs + u * TILE;
@@ -415,13 +426,14 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
         const unsigned voff = (unsigned)(row * nao + 2 * seg) * 8u;
         auto issue_ao = [&](int set, long s) {
             const long row0 = (blockIdx.x + min(s, nloc - 1) * gridDim.x) * WS_ROWS; // wave-uniform
-            buf_load_row<C::JN, VEC>(plane_tile_rsrc(ao, plane, row0 * nao), voff, ph[set]);
+            buf_load_row<C::JN, VEC>(plane_tile_rsrc(ao, plane, row0 * nao, s < nloc), voff, ph[set]);
         };
         auto issue_grad = [&](int set, long s) {
             const long e0 = (blockIdx.x + min(s, nloc - 1) * gridDim.x) * WS_ROWS * (long)nao;
-            buf_load_row<C::JN, VEC>(plane_tile_rsrc(gx, plane, e0), voff, pgx[set]);
-            buf_load_row<C::JN, VEC>(plane_tile_rsrc(gy, plane, e0), voff, pgy[set]);
-            buf_load_row<C::JN, VEC>(plane_tile_rsrc(gz, plane, e0), voff, pgz[set]);
+            const bool live = s < nloc;
+            buf_load_row<C::JN, VEC>(plane_tile_rsrc(gx, plane, e0, live), voff, pgx[set]);
+            buf_load_row<C::JN, VEC>(plane_tile_rsrc(gy, plane, e0, live), voff, pgy[set]);
+            buf_load_row<C::JN, VEC>(plane_tile_rsrc(gz, plane, e0, live), voff, pgz[set]);
         };
         issue_ao(0, 0);
         issue_ao(1, 1);

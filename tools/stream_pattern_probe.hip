@@ -41,6 +41,7 @@ template<int THREADS,int DEPTH> void run(int wgs_per_cu,int ncu,long ngrid,int n
 int main(){
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop,0)); int ncu=prop.multiProcessorCount;
   long ngrid=143556; int nao=114; size_t plane=(size_t)ngrid*nao; double* p; CK(hipMalloc(&p,plane*8*4+4096)); CK(hipMemset(p,0,plane*8*4)); double* out; CK(hipMalloc(&out,64));
+  run<256,1>(1,ncu,ngrid,nao,p,out); run<256,2>(1,ncu,ngrid,nao,p,out); run<256,3>(1,ncu,ngrid,nao,p,out); run<128,2>(1,ncu,ngrid,nao,p,out);
   run<512,1>(1,ncu,ngrid,nao,p,out); run<512,2>(1,ncu,ngrid,nao,p,out);
   run<512,1>(2,ncu,ngrid,nao,p,out); run<512,1>(4,ncu,ngrid,nao,p,out);
   run<256,1>(2,ncu,ngrid,nao,p,out); run<256,1>(4,ncu,ngrid,nao,p,out); run<256,2>(4,ncu,ngrid,nao,p,out); run<256,1>(8,ncu,ngrid,nao,p,out);
