@@ -172,9 +172,18 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     const int nA = (nao + BG_BM - 1) / BG_BM, nB = (nao + BG_BN - 1) / BG_BN, npair = nA * nB;
     if (big) {
         // split-K over grid chunks; chunks are dealt to XCDs (blockIdx % 8), so ksplit is a multiple of 8
-        long per_xcd = std::max(1, (s->num_cu / 8) / npair);
-        const long max_chunks = (ngrid + BG_BK - 1) / BG_BK;
-        while (per_xcd > 1 && 8 * per_xcd > max_chunks) per_xcd >>= 1;
+        // chunks per XCD: the candidate (<= 32, slabs <= 2 GB, >= 64 grid rows per chunk) whose workgroup
+        // count fills whole waves of the chip best (360 workgroups on 256 CUs lost 30 % to the tail)
+        long per_xcd = 1;
+        double best = 0.0;
+        for (long c = 1; c <= 32; ++c) {
+            const long wgs = 8L * npair * c;
+            if (8 * c * 64 > ngrid && c > 1) break;
+            if ((double)(8 * c) * nao * nao * 8.0 > 2.0e9 && c > 1) break;
+            const long rounds = (wgs + s->num_cu - 1) / s->num_cu;
+            const double eff = (double)wgs / (double)(rounds * s->num_cu);
+            if (eff > best + 1e-9) { best = eff; per_xcd = c; }
+        }
         nslab = (int)(8 * per_xcd);
         chunk = (ngrid + nslab - 1) / nslab;
         chunk = ((chunk + BG_BK - 1) / BG_BK) * BG_BK;

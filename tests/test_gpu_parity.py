@@ -299,3 +299,23 @@ def test_full_scf_matches_the_oracle_driven_scf(dev, fn, bname):
     assert r_gpu["E_tot"] == pytest.approx(r_cpu["E_tot"], abs=1e-9)
     assert r_gpu["E_xc"] == pytest.approx(r_cpu["E_xc"], abs=1e-9)
     assert np.abs(r_gpu["dm"] - r_cpu["dm"]).max() < 1e-7
+
+
+def test_more_than_2_31_ao_elements(dev):
+    """ngrid*nao = 2.4e9 > 2^31 (the reference's int products overflow at 2^30, dft_solver.cu:597,634).
+    The AO array is a small block repeated R times, so Exc and V must be exactly R x the block's
+    (checked against the oracle on the block)."""
+    nao, nblk, R = 8, 3000, 100000          # 300 M grid points, 19.2 GB of AO values
+    dm, ao, _, w = synth_inputs(nblk, nao, need_grad=False, seed=41)
+    exc_ref, v_ref = oracle.compute_xc(0, dm, ao, w)
+    d_ao = torch.as_tensor(ao, device=dev).repeat(R, 1).contiguous()
+    d_w = torch.as_tensor(w, device=dev).repeat(R).contiguous()
+    ngrid = nblk * R
+    assert d_ao.numel() > 2 ** 31
+    sv = _solver(0)
+    d_v = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
+    exc = sv.compute_xc(ngrid, nao, torch.as_tensor(dm, device=dev), d_ao, d_w, d_v, None)
+    assert exc == pytest.approx(R * exc_ref, rel=1e-10)
+    assert np.abs(d_v.cpu().numpy() - R * v_ref).max() <= 1e-9 * R * np.abs(v_ref).max()
+    del d_ao, d_w
+    torch.cuda.empty_cache()

@@ -29,6 +29,9 @@ time_xc("Benzene B3LYP def2-SVP", "B3LYP", 114, 143556)
 time_xc("Anthracene B3LYP sto-3g", "B3LYP", 80, 294868)
 time_xc("Anthracene B3LYP def2-SVP", "B3LYP", 246, 294868, reps=3)
 time_xc("Anthracene B3LYP def2-TZVP", "B3LYP", 494, 294868, reps=3)
+if "--config5" in sys.argv:
+    time_xc("C33H56N7O17P3S B3LYP def2-SVP (1 GPU)", "B3LYP", 1150, 1436406, reps=2)
+    sys.exit(0)
 
 # J / K on the dense ERI
 for n in (36, 80, 114):
