@@ -11,67 +11,75 @@
 //   S_lm = real solid harmonics, order  p: x,y,z;  d: xy,yz,z2,xz,x2-y2;
 //   f: m=-3..3  (y(3x2-y2), xyz, y(4z2-x2-y2), z(2z2-3x2-3y2), x(4z2-x2-y2), z(x2-y2), x(x2-3y2)).
 //
-// Mapping: workgroup = 64 grid points (lane = point), the four waves split the
-// shells of one <=32-column chunk; results go to an LDS tile [point][col]
-// (ld 33: conflict-free both for lane=point writes and lane=column reads) and
-// leave as contiguous row segments.  Shell parameters are wave-uniform
-// (scalar loads).  HBM-write bound: 8*nao*(1 or 4) bytes per grid point.
+// The kernel is HBM-WRITE bound (8*nao*(1 or 4) bytes per grid point against ~100 flops per
+// primitive), and what matters is how the rows leave the chip.  A first version wrote
+// 32-column chunks: with four planes in flight the partial 128-byte lines it left for the
+// next chunk cost 2.6 TB/s (stores alone 200 us of 213 for Benzene/def2-SVP, compute 61 us).
+// Now a workgroup owns 16 grid points x a column block of <= 128 columns (the whole row for
+// nao <= 128): every plane's tile is staged in LDS and leaves as complete rows, 16 lanes
+// writing 256 contiguous bytes with 16-byte stores, all column groups of a row back to back.
+// Compute mapping: lane = (point = lane & 15, shell slot = lane >> 4), 16 shells per pass over
+// the 4 waves; the host orders the shells of a block by (l, nprim) so the four shells a wave
+// evaluates together mostly share one code path.  Shell data are per-lane loads (L1/L2 hits).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace qcdft {
 
 constexpr int AO_MAX_L = 3;
-constexpr int AO_CT = 32;  // columns per chunk
-constexpr int AO_LD = 33;  // LDS leading dimension
-constexpr int AO_G = 64;   // grid points per workgroup
+constexpr int AO_PT = 16;    // grid points per workgroup
+constexpr int AO_CW = 126;   // max columns per block (4 planes x 16 x 127 doubles < 64 KB)
 
 struct AoShell {
     double x, y, z;
     int l, nprim, off, ao;
 };
-struct AoChunk {
+struct AoChunk { // one column block: shells [shell_lo, shell_hi), columns [col_lo, col_lo + ncol)
     int shell_lo, shell_hi, col_lo, ncol;
 };
 
 template <bool GRAD>
-__device__ __forceinline__ void ao_put(double *tile, int idx, double S, double Sx, double Sy,
-                                       double Sz, double R0, double R1, double dx, double dy,
-                                       double dz)
+__device__ __forceinline__ void ao_put(double *tile, int plane_sz, int idx, double S, double Sx,
+                                       double Sy, double Sz, double R0, double R1, double dx,
+                                       double dy, double dz)
 {
     tile[idx] = R0 * S;
     if (GRAD) {
         const double t = R1 * S;
-        tile[AO_G * AO_LD + idx] = R0 * Sx + t * dx;
-        tile[2 * AO_G * AO_LD + idx] = R0 * Sy + t * dy;
-        tile[3 * AO_G * AO_LD + idx] = R0 * Sz + t * dz;
+        tile[plane_sz + idx] = R0 * Sx + t * dx;
+        tile[2 * plane_sz + idx] = R0 * Sy + t * dy;
+        tile[3 * plane_sz + idx] = R0 * Sz + t * dz;
     }
 }
 
-template <bool GRAD>
-__global__ __launch_bounds__(256) void k_eval_ao(long ngrid, int nao, int nchunk,
+// order[k], k in [shell_lo, shell_hi): shell indices of the block sorted by (l, nprim).
+// ldt: LDS leading dimension (odd, >= widest block).  Dynamic LDS: (GRAD?4:1)*AO_PT*ldt doubles.
+template <bool GRAD, bool VEC>
+__global__ __launch_bounds__(256) void k_eval_ao(long ngrid, int nao, int nchunk, int ldt,
                                                  const AoShell *__restrict__ sh,
                                                  const double *__restrict__ pexp,
                                                  const double *__restrict__ pcoef,
                                                  const AoChunk *__restrict__ chunks,
+                                                 const int *__restrict__ order,
                                                  const double *__restrict__ coords,
                                                  double *__restrict__ ao,
                                                  double *__restrict__ grad)
 {
-    __shared__ double tile[(GRAD ? 4 : 1) * AO_G * AO_LD];
+    extern __shared__ double tile[];
+    const int plane_sz = AO_PT * ldt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long g0 = (long)blockIdx.x * AO_G;
-    const long g = g0 + lane;
-    double px = 0, py = 0, pz = 0;
-    if (g < ngrid) {
-        px = coords[3 * g];
-        py = coords[3 * g + 1];
-        pz = coords[3 * g + 2];
-    }
+    const int pt = lane & 15, slot = wave * 4 + (lane >> 4); // 16 points x 16 shell slots
+    const long g0 = (long)blockIdx.x * AO_PT;
+    const long g = min(g0 + pt, ngrid - 1);
+    const double px = coords[3 * g], py = coords[3 * g + 1], pz = coords[3 * g + 2];
+    // store mapping: row = tid >> 4, columns 32j + 2*(tid & 15) + {0,1}
+    const int srow = tid >> 4, sseg = tid & 15;
+    const long grow = g0 + srow;
+
     for (int ci = 0; ci < nchunk; ++ci) {
         const AoChunk ch = chunks[ci];
-        for (int s = ch.shell_lo + wave; s < ch.shell_hi; s += 4) {
-            const AoShell q = sh[s];
+        for (int k = ch.shell_lo + slot; k < ch.shell_hi; k += 16) {
+            const AoShell q = sh[order[k]];
             const double x = px - q.x, y = py - q.y, z = pz - q.z;
             const double r2 = x * x + y * y + z * z;
             double R0 = 0.0, R1 = 0.0;
@@ -81,62 +89,71 @@ __global__ __launch_bounds__(256) void k_eval_ao(long ngrid, int nao, int nchunk
                 R0 += e;
                 R1 -= 2.0 * a * e;
             }
-            const int i0 = lane * AO_LD + (q.ao - ch.col_lo);
+            const int i0 = pt * ldt + (q.ao - ch.col_lo);
             if (q.l == 0) {
                 constexpr double c = 0.282094791773878143;
-                ao_put<GRAD>(tile, i0, c, 0, 0, 0, R0, R1, x, y, z);
+                ao_put<GRAD>(tile, plane_sz, i0, c, 0, 0, 0, R0, R1, x, y, z);
             } else if (q.l == 1) {
                 constexpr double c = 0.488602511902919921;
-                ao_put<GRAD>(tile, i0 + 0, c * x, c, 0, 0, R0, R1, x, y, z);
-                ao_put<GRAD>(tile, i0 + 1, c * y, 0, c, 0, R0, R1, x, y, z);
-                ao_put<GRAD>(tile, i0 + 2, c * z, 0, 0, c, R0, R1, x, y, z);
+                ao_put<GRAD>(tile, plane_sz, i0 + 0, c * x, c, 0, 0, R0, R1, x, y, z);
+                ao_put<GRAD>(tile, plane_sz, i0 + 1, c * y, 0, c, 0, R0, R1, x, y, z);
+                ao_put<GRAD>(tile, plane_sz, i0 + 2, c * z, 0, 0, c, R0, R1, x, y, z);
             } else if (q.l == 2) {
                 constexpr double c = 1.092548430592079070, d = 0.315391565252520002,
                                  e = 0.546274215296039535;
-                ao_put<GRAD>(tile, i0 + 0, c * x * y, c * y, c * x, 0, R0, R1, x, y, z);
-                ao_put<GRAD>(tile, i0 + 1, c * y * z, 0, c * z, c * y, R0, R1, x, y, z);
-                ao_put<GRAD>(tile, i0 + 2, d * (2 * z * z - x * x - y * y), -2 * d * x, -2 * d * y,
-                             4 * d * z, R0, R1, x, y, z);
-                ao_put<GRAD>(tile, i0 + 3, c * x * z, c * z, 0, c * x, R0, R1, x, y, z);
-                ao_put<GRAD>(tile, i0 + 4, e * (x * x - y * y), 2 * e * x, -2 * e * y, 0, R0, R1, x,
-                             y, z);
+                ao_put<GRAD>(tile, plane_sz, i0 + 0, c * x * y, c * y, c * x, 0, R0, R1, x, y, z);
+                ao_put<GRAD>(tile, plane_sz, i0 + 1, c * y * z, 0, c * z, c * y, R0, R1, x, y, z);
+                ao_put<GRAD>(tile, plane_sz, i0 + 2, d * (2 * z * z - x * x - y * y), -2 * d * x,
+                             -2 * d * y, 4 * d * z, R0, R1, x, y, z);
+                ao_put<GRAD>(tile, plane_sz, i0 + 3, c * x * z, c * z, 0, c * x, R0, R1, x, y, z);
+                ao_put<GRAD>(tile, plane_sz, i0 + 4, e * (x * x - y * y), 2 * e * x, -2 * e * y, 0,
+                             R0, R1, x, y, z);
             } else {
                 constexpr double f3 = 0.590043589926643510, f2 = 2.890611442640554055,
                                  f1 = 0.457045799464465739, f0 = 0.373176332590115391,
                                  f2b = 1.445305721320277020;
                 const double xx = x * x, yy = y * y, zz = z * z;
-                ao_put<GRAD>(tile, i0 + 0, f3 * y * (3 * xx - yy), f3 * 6 * x * y,
+                ao_put<GRAD>(tile, plane_sz, i0 + 0, f3 * y * (3 * xx - yy), f3 * 6 * x * y,
                              f3 * (3 * xx - 3 * yy), 0, R0, R1, x, y, z);
-                ao_put<GRAD>(tile, i0 + 1, f2 * x * y * z, f2 * y * z, f2 * x * z, f2 * x * y, R0,
-                             R1, x, y, z);
-                ao_put<GRAD>(tile, i0 + 2, f1 * y * (4 * zz - xx - yy), -2 * f1 * x * y,
+                ao_put<GRAD>(tile, plane_sz, i0 + 1, f2 * x * y * z, f2 * y * z, f2 * x * z,
+                             f2 * x * y, R0, R1, x, y, z);
+                ao_put<GRAD>(tile, plane_sz, i0 + 2, f1 * y * (4 * zz - xx - yy), -2 * f1 * x * y,
                              f1 * (4 * zz - xx - 3 * yy), 8 * f1 * y * z, R0, R1, x, y, z);
-                ao_put<GRAD>(tile, i0 + 3, f0 * z * (2 * zz - 3 * xx - 3 * yy), -6 * f0 * x * z,
-                             -6 * f0 * y * z, f0 * (6 * zz - 3 * xx - 3 * yy), R0, R1, x, y, z);
-                ao_put<GRAD>(tile, i0 + 4, f1 * x * (4 * zz - xx - yy), f1 * (4 * zz - 3 * xx - yy),
-                             -2 * f1 * x * y, 8 * f1 * x * z, R0, R1, x, y, z);
-                ao_put<GRAD>(tile, i0 + 5, f2b * z * (xx - yy), 2 * f2b * x * z, -2 * f2b * y * z,
-                             f2b * (xx - yy), R0, R1, x, y, z);
-                ao_put<GRAD>(tile, i0 + 6, f3 * x * (xx - 3 * yy), f3 * (3 * xx - 3 * yy),
+                ao_put<GRAD>(tile, plane_sz, i0 + 3, f0 * z * (2 * zz - 3 * xx - 3 * yy),
+                             -6 * f0 * x * z, -6 * f0 * y * z, f0 * (6 * zz - 3 * xx - 3 * yy), R0,
+                             R1, x, y, z);
+                ao_put<GRAD>(tile, plane_sz, i0 + 4, f1 * x * (4 * zz - xx - yy),
+                             f1 * (4 * zz - 3 * xx - yy), -2 * f1 * x * y, 8 * f1 * x * z, R0, R1,
+                             x, y, z);
+                ao_put<GRAD>(tile, plane_sz, i0 + 5, f2b * z * (xx - yy), 2 * f2b * x * z,
+                             -2 * f2b * y * z, f2b * (xx - yy), R0, R1, x, y, z);
+                ao_put<GRAD>(tile, plane_sz, i0 + 6, f3 * x * (xx - 3 * yy), f3 * (3 * xx - 3 * yy),
                              -6 * f3 * x * y, 0, R0, R1, x, y, z);
             }
         }
         __syncthreads();
-        {
-            const int c = tid & 31, r0 = tid >> 5;
-            if (c < ch.ncol) {
+        if (grow < ngrid) {
+            const size_t rbase = (size_t)grow * nao + ch.col_lo;
+            const size_t plane = (size_t)ngrid * nao;
+            const double *t0 = tile + srow * ldt;
+            for (int c = 2 * sseg; c < ch.ncol; c += 32) {
+                if (VEC && c + 1 < ch.ncol) { // nao and col_lo even, 16-byte aligned outputs (host-checked)
+                    *reinterpret_cast<double2 *>(ao + rbase + c) = make_double2(t0[c], t0[c + 1]);
+                    if (GRAD) {
+                        *reinterpret_cast<double2 *>(grad + rbase + c) = make_double2(t0[plane_sz + c], t0[plane_sz + c + 1]);
+                        *reinterpret_cast<double2 *>(grad + plane + rbase + c) = make_double2(t0[2 * plane_sz + c], t0[2 * plane_sz + c + 1]);
+                        *reinterpret_cast<double2 *>(grad + 2 * plane + rbase + c) = make_double2(t0[3 * plane_sz + c], t0[3 * plane_sz + c + 1]);
+                    }
+                } else {
 #pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    const int r = r0 + 8 * p;
-                    const long gr = g0 + r;
-                    if (gr < ngrid) {
-                        const size_t o = (size_t)gr * nao + ch.col_lo + c;
-                        ao[o] = tile[r * AO_LD + c];
-                        if (GRAD) {
-                            const size_t plane = (size_t)ngrid * nao;
-                            grad[o] = tile[AO_G * AO_LD + r * AO_LD + c];
-                            grad[plane + o] = tile[2 * AO_G * AO_LD + r * AO_LD + c];
-                            grad[2 * plane + o] = tile[3 * AO_G * AO_LD + r * AO_LD + c];
+                    for (int d = 0; d < 2; ++d) {
+                        if (c + d < ch.ncol) {
+                            ao[rbase + c + d] = t0[c + d];
+                            if (GRAD) {
+                                grad[rbase + c + d] = t0[plane_sz + c + d];
+                                grad[plane + rbase + c + d] = t0[2 * plane_sz + c + d];
+                                grad[2 * plane + rbase + c + d] = t0[3 * plane_sz + c + d];
+                            }
                         }
                     }
                 }
@@ -146,15 +163,21 @@ __global__ __launch_bounds__(256) void k_eval_ao(long ngrid, int nao, int nchunk
     }
 }
 
-inline void launch_eval_ao(hipStream_t st, long ngrid, int nao, int nchunk, const AoShell *sh,
-                           const double *pexp, const double *pcoef, const AoChunk *chunks,
-                           const double *coords, double *ao, double *grad)
+inline void launch_eval_ao(hipStream_t st, long ngrid, int nao, int nchunk, int maxcol, bool vec,
+                           const AoShell *sh, const double *pexp, const double *pcoef,
+                           const AoChunk *chunks, const int *order, const double *coords, double *ao,
+                           double *grad)
 {
-    dim3 g((unsigned)((ngrid + AO_G - 1) / AO_G));
-    if (grad)
-        hipLaunchKernelGGL(k_eval_ao<true>, g, dim3(256), 0, st, ngrid, nao, nchunk, sh, pexp, pcoef, chunks, coords, ao, grad);
-    else
-        hipLaunchKernelGGL(k_eval_ao<false>, g, dim3(256), 0, st, ngrid, nao, nchunk, sh, pexp, pcoef, chunks, coords, ao, grad);
+    dim3 g((unsigned)((ngrid + AO_PT - 1) / AO_PT));
+    const int ldt = maxcol | 1;
+    const size_t lds = sizeof(double) * (grad ? 4 : 1) * AO_PT * ldt;
+    if (grad) {
+        if (vec) hipLaunchKernelGGL((k_eval_ao<true, true>), g, dim3(256), lds, st, ngrid, nao, nchunk, ldt, sh, pexp, pcoef, chunks, order, coords, ao, grad);
+        else     hipLaunchKernelGGL((k_eval_ao<true, false>), g, dim3(256), lds, st, ngrid, nao, nchunk, ldt, sh, pexp, pcoef, chunks, order, coords, ao, grad);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_eval_ao<false, true>), g, dim3(256), lds, st, ngrid, nao, nchunk, ldt, sh, pexp, pcoef, chunks, order, coords, ao, grad);
+        else     hipLaunchKernelGGL((k_eval_ao<false, false>), g, dim3(256), lds, st, ngrid, nao, nchunk, ldt, sh, pexp, pcoef, chunks, order, coords, ao, grad);
+    }
 }
 
 } // namespace qcdft

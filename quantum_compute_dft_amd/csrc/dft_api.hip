@@ -476,7 +476,7 @@ int DFT_EvalAO(XCSolver *s, long long ngrid, int nao, int nshell, const double *
         set_error(s, "bad AO sizes");
         return -1;
     }
-    // validate, then pack: [AoShell x nshell][exp x nprim][coef x nprim][AoChunk x nchunk]
+    // validate, then pack: [AoShell x nshell][exp x nprim][coef x nprim][AoChunk x nchunk][order x nshell]
     int next_col = 0;
     std::vector<AoChunk> chunks;
     for (int i = 0; i < nshell; ++i) {
@@ -484,17 +484,42 @@ int DFT_EvalAO(XCSolver *s, long long ngrid, int nao, int nshell, const double *
         if (l < 0 || l > AO_MAX_L) { set_error(s, "shell %d: l=%d unsupported (max %d)", i, l, AO_MAX_L); return -1; }
         if (shl_nprim[i] <= 0 || shl_off[i] < 0 || shl_off[i] + shl_nprim[i] > nprim_total) { set_error(s, "shell %d: primitive range out of bounds", i); return -1; }
         if (shl_ao[i] != next_col) { set_error(s, "shell %d: AO columns must be contiguous and ascending (expected %d, got %d)", i, next_col, shl_ao[i]); return -1; }
-        if (chunks.empty() || chunks.back().ncol + nf > AO_CT)
+        if (chunks.empty()) {
             chunks.push_back(AoChunk{i, i, next_col, 0});
+        } else if (chunks.back().ncol + nf > AO_CW) {
+            // new column block; keep its first column even (16-byte stores) by taking the previous
+            // shell along when needed -- every shell has an odd width, so that flips the parity
+            AoChunk &b = chunks.back();
+            if ((next_col & 1) && b.shell_hi - b.shell_lo >= 2) {
+                const int pf = 2 * shl_l[i - 1] + 1;
+                b.shell_hi -= 1;
+                b.ncol -= pf;
+                chunks.push_back(AoChunk{i - 1, i, next_col - pf, pf});
+            } else {
+                chunks.push_back(AoChunk{i, i, next_col, 0});
+            }
+        }
         chunks.back().shell_hi = i + 1;
         chunks.back().ncol += nf;
         next_col += nf;
     }
     if (next_col != nao) { set_error(s, "shell table covers %d AO columns, nao=%d", next_col, nao); return -1; }
     const int nchunk = (int)chunks.size();
+    int maxcol = 0;
+    bool vec = (nao % 2 == 0) && (d_ao % 16 == 0) && (d_ao_grad % 16 == 0);
+    std::vector<int> order(nshell);
+    for (const AoChunk &c : chunks) {
+        maxcol = std::max(maxcol, c.ncol);
+        if (c.col_lo & 1) vec = false;
+        for (int i = c.shell_lo; i < c.shell_hi; ++i) order[i] = i;
+        std::stable_sort(order.begin() + c.shell_lo, order.begin() + c.shell_hi, [&](int a, int b) {
+            return shl_l[a] != shl_l[b] ? shl_l[a] < shl_l[b] : shl_nprim[a] < shl_nprim[b];
+        });
+    }
     const size_t off_exp = sizeof(AoShell) * nshell;
     const size_t off_chunk = off_exp + 2 * sizeof(double) * nprim_total;
-    const size_t bytes = off_chunk + sizeof(AoChunk) * nchunk;
+    const size_t off_order = off_chunk + sizeof(AoChunk) * nchunk;
+    const size_t bytes = off_order + sizeof(int) * nshell;
     std::vector<unsigned char> blob(bytes);
     AoShell *sh = (AoShell *)blob.data();
     for (int i = 0; i < nshell; ++i) {
@@ -505,6 +530,7 @@ int DFT_EvalAO(XCSolver *s, long long ngrid, int nao, int nshell, const double *
     memcpy(pe, prim_exp, sizeof(double) * nprim_total);
     memcpy(pe + nprim_total, prim_coef, sizeof(double) * nprim_total);
     memcpy(blob.data() + off_chunk, chunks.data(), sizeof(AoChunk) * nchunk);
+    memcpy(blob.data() + off_order, order.data(), sizeof(int) * nshell);
     if (blob != s->shell_blob) {
         if (!reserve(s, s->shells, bytes, "hipMalloc(shells)")) return -1;
         if (!hip_ok(s, hipMemcpyAsync(s->shells.p, blob.data(), bytes, hipMemcpyHostToDevice, s->stream), "upload shells") ||
@@ -517,7 +543,8 @@ int DFT_EvalAO(XCSolver *s, long long ngrid, int nao, int nshell, const double *
     const double *dexp = (const double *)(base + off_exp);
     const double *dcoef = dexp + nprim_total;
     const AoChunk *dchunks = (const AoChunk *)(base + off_chunk);
-    launch_eval_ao(s->stream, (long)ngrid, nao, nchunk, dsh, dexp, dcoef, dchunks,
+    const int *dorder = (const int *)(base + off_order);
+    launch_eval_ao(s->stream, (long)ngrid, nao, nchunk, maxcol, vec, dsh, dexp, dcoef, dchunks, dorder,
                    (const double *)d_coords, (double *)d_ao, (double *)d_ao_grad);
     return hip_ok(s, hipGetLastError(), "AO launch") ? 0 : -1;
 }

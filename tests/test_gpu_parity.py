@@ -226,6 +226,13 @@ def test_coulomb_and_exchange_match_oracle(dev, n):
     ("def2-svp", "O 0 0 0.1173; H 0 0.7572 -0.4692; H 0 -0.7572 -0.4692", 1),
     ("def2-svp", "C 0 0 0; C 1.39 0 0; N 0 1.4 0.2; H -0.9 -0.5 0.1; O 2.1 1.1 -0.3", 0),
     ("f-mix", "C 0 0 0; O 1.1 0.2 0; H -0.6 0.8 0.3", 1),
+    # more than one column block (nao 142 even / 141 odd): block seams and both store widths
+    ("def2-svp", "C 0 0 0; C 1.4 0 0; C 2.1 1.2 0; C 1.4 2.4 0; C 0 2.4 0; C -0.7 1.2 0; N 3.5 1.2 0.1; O -2.1 1.2 -0.1;"
+                 " H -0.5 -0.9 0; H 1.9 -0.9 0; H 1.9 3.3 0; H -0.5 3.3 0; H 4.0 2.0 0.3; H 4.0 0.4 0.3", 1),
+    ("def2-svp", "C 0 0 0; C 1.4 0 0; C 2.1 1.2 0; C 1.4 2.4 0; C 0 2.4 0; C -0.7 1.2 0; N 3.5 1.2 0.1; O -2.1 1.2 -0.1;"
+                 " O 0.7 1.2 3.0; H -0.5 -0.9 0; H 1.9 -0.9 0; H 1.9 3.3 0", 1),
+    ("def2-svp", "C 0 0 0; C 1.4 0 0; C 2.1 1.2 0; C 1.4 2.4 0; C 0 2.4 0; C -0.7 1.2 0; N 3.5 1.2 0.1; O -2.1 1.2 -0.1;"
+                 " O 0.7 1.2 3.0; H -0.5 -0.9 0; H 1.9 -0.9 0; H 1.9 3.3 0", 0),
 ])
 def test_eval_ao_matches_oracle(dev, bname, mol, deriv):
     if bname == "f-mix":
