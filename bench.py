@@ -151,6 +151,35 @@ def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=5):
             "note": "synthetic dm/ERI; J" + ("+K one pass" if xc == "B3LYP" else "") + ", XC, host eigh (scipy) as in dft.py:199-236"}
 
 
+def k_build_mfma(lib_path, dev, nao=494, nocc=47, naux=3000, reps=5):
+    """Exact-exchange build on the fp64 matrix cores (north_star (d)): DFT_ComputeJKFactorized on synthetic
+    Cholesky vectors of the Anthracene/def2-TZVP shape (dense ERI there: 476 GB).  Useful flops
+    4 naux nao^2 nocc (half transform + Yt^T Yt), kernel times from HIP events inside the library."""
+    g = torch.Generator(device=dev); g.manual_seed(SEED)
+    L = torch.randn((naux, nao, nao), dtype=torch.float64, device=dev, generator=g) * 0.1
+    c = torch.randn((nao, nocc), dtype=torch.float64, device=dev, generator=g)
+    dm = c @ c.T
+    J = torch.zeros((nao, nao), dtype=torch.float64, device=dev); K = torch.zeros_like(J)
+    s = q.DFTSolverWrapper(lib_path, "B3LYP")
+    s.set_option("profile", 1)
+    acc = {}
+    for it in range(reps + 2):
+        s.compute_jk_factorized(nao, naux, nocc, L, dm, c, J, K)
+        torch.cuda.synchronize()
+        if it >= 2:
+            for k, v in s.timings():
+                acc[k] = acc.get(k, 0.0) + v / reps
+    fl = 2.0 * naux * nao * nao * nocc
+    t_k = acc["cd_half"] + acc["cd_k"]
+    del L, s
+    torch.cuda.empty_cache()
+    return {"workload": f"anthracene_b3lyp_def2tzvp shape: nao={nao} nocc={nocc} naux={naux} synthetic Cholesky vectors "
+                        f"({8.0 * naux * nao * nao / 1e9:.2f} GB resident)",
+            "kernels_ms": acc, "k_ms": t_k, "flops": 2 * fl,
+            "achieved": 2 * fl / t_k / 1e9, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": 2 * fl / t_k / 1e9 / F64_MFMA_PEAK_TF,
+            "j_pass_gbs": 8.0 * naux * nao * nao / acc["cd_j"] / 1e6}
+
+
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled
     per the gfx950 correction, + WRITE_SIZE); None when no profile matches this workload."""
@@ -173,6 +202,7 @@ def main():
     ap.add_argument("--workload", default="benzene_gga_def2svp", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-k-build", action="store_true", help="skip the factorised exact-exchange (fp64 MFMA) measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo only to rehearse N>1 on a single card")
     args = ap.parse_args()
@@ -281,6 +311,8 @@ def main():
             si = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev)
             if si:
                 line["scf_iteration"] = si
+        if world == 1 and not args.no_k_build:
+            line["k_build"] = k_build_mfma(q.build_library(), dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(xc, dm, ao, gr, w, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -99,6 +99,22 @@ void DFT_ComputeJK(XCSolver *solver, int nao,
                    unsigned long long d_J_ptr,
                    unsigned long long d_K_ptr);
 
+/* J and K from a factorised ERI, (ij|kl) ~= sum_P L[P][i][j] L[P][k][l] (pivoted
+ * Cholesky vectors, d_chol_ptr: (naux, nao, nao) f64 C-order, every L[P] symmetric).
+ * Same matrices as DFT_ComputeCoulomb (dft_solver.cu:550-555, dft.py:203) and the
+ * exchange einsum (dft.py:218) to within the factorisation threshold, for basis sizes
+ * whose dense ERI (8 nao^4 bytes) does not fit in HBM; K runs as fp64 MFMA GEMMs.
+ * d_cocc_ptr: (nao, nocc) f64 C-order with dm = cocc . cocc^T (occupation folded in,
+ * i.e. sqrt(2) C_occ for the closed-shell dm of dft.py:181-182).  d_J_ptr or d_K_ptr
+ * may be 0; J needs d_dm_ptr, K needs d_cocc_ptr.  Asynchronous; returns 0 or -1
+ * (DFT_GetLastError). */
+int DFT_ComputeJKFactorized(XCSolver *solver, int nao, int naux, int nocc,
+                            unsigned long long d_chol_ptr,
+                            unsigned long long d_dm_ptr,
+                            unsigned long long d_cocc_ptr,
+                            unsigned long long d_J_ptr,
+                            unsigned long long d_K_ptr);
+
 /* AO values (and Cartesian gradients) on the grid: replaces PySCF's
  * dft.numint.eval_ao(mol, coords, deriv=0/1) at grid.py:30,38.
  * Shell table (host pointers, copied to the device on first use / change):

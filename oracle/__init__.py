@@ -4,5 +4,5 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this package.  The product package (quantum_compute_dft_amd) never does.
 """
 from .loader import (  # noqa: F401
-    build, lib, compute_xc, coulomb, exchange, pointwise, eval_ao, POINTWISE_KINDS,
+    build, lib, compute_xc, coulomb, exchange, jk_from_factors, pointwise, eval_ao, POINTWISE_KINDS,
 )

@@ -91,6 +91,16 @@ def exchange(eri, dm):
     return K
 
 
+def jk_from_factors(chol, dm):
+    """J and K of dft.py:203,218 with the ERI replaced by its factorisation sum_P L_P (x) L_P:
+    J = sum_P (L_P : dm) L_P,  K = sum_P L_P dm L_P  -- straight from dm (no occupied orbitals),
+    so it checks the device's Cocc route independently.  numpy, small cases only."""
+    chol, dm = _c(chol), _c(dm)
+    J = np.einsum("pij,p->ij", chol, np.einsum("pij,ij->p", chol, dm))
+    K = np.einsum("pik,kl,pjl->ij", chol, dm, chol, optimize=True)
+    return J, K
+
+
 def pointwise(kind, rho, sigma=None, quirks=True):
     """(n,3) array of (e, vrho, vsigma) for one functional kind (name or id)."""
     k = POINTWISE_KINDS[kind] if isinstance(kind, str) else int(kind)

@@ -1,0 +1,217 @@
+// J and K from a factorised ERI,  (ij|kl) ~= sum_P L[P][i][j] L[P][k][l]   (SURVEY 8(f4)).
+//
+// The reference contracts the dense (nao^2, nao^2) ERI (J: dft_solver.cu:550-555, K: the einsum at
+// dft.py:217-221), 8 nao^4 bytes that stop fitting in 288 GB at nao ~ 430.  With Cholesky vectors
+// L (naux, nao, nao) the same matrices are
+//     J      = sum_P (L_P : D) L_P                                  two HBM passes over L
+//     Yt_P   = Cocc^T L_P                    (nocc x nao)            fp64 MFMA, 2 naux nao^2 nocc flop
+//     K      = sum_P Yt_P^T Yt_P = Yt^T Yt,  Yt ((naux nocc) x nao)  fp64 MFMA, 2 naux nao^2 nocc flop
+// with D = Cocc Cocc^T (occupation folded into Cocc).  This is the only formulation in which the
+// exchange build is matrix-core work.
+//
+// Both MFMA steps are the same "TN" tile GEMM, C = A^T B with the contraction index on the rows of
+// both row-major operands: 512 threads = 8 waves, BK = 16, LDS double-buffered, the next stage's
+// range-checked buffer loads issued before the current stage's MFMAs (same skeleton as
+// k_vxc_big).  Tile 128 x 256 (wave tile 64 x 64) for the Yt^T Yt step, split over the contraction
+// index across workgroups of one XCD group with per-chunk slabs summed in fixed order; tile
+// 64 x 256 (wave tile 16*MI x 32) for the half transform when nocc <= 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "xc_big_kernels.hpp"
+
+namespace qcdft {
+
+constexpr int CD_BN = 256, CD_BK = 16, CD_LDB = CD_BN + 16; // 272 = 16 (mod 32)
+
+// C[batch][chunk](M x N) = sum_{g in chunk} A[batch][g][a] * B[batch][g][b]
+//   WGM = 2: tile 128 x 256, MI = 4.   WGM = 1: tile 64 x 256, MI = ceil(min(M,64)/16) row tiles live.
+//   split = true : blockIdx.x -> (xcd = b % 8, slot = b / 8), pair = slot % npair, chunk = xcd + 8 (slot / npair), batch 0
+//   split = false: pair = b % npair, batch = b / npair, one chunk covering [0, G)
+// Rows of A/B past the chunk end read as zeros (descriptor range), columns past M/N only feed
+// discarded outputs.
+// DOT (half transform only, split = false): the B tiles are the Cholesky vectors themselves, so the
+// workgroups of a-block 0 also accumulate sum B[g][b] * Dm[g][b] over their tile while it passes
+// through registers and leave one partial of v_P = L_P : D per (P, b-block) in vpart -- the first of
+// J's two passes over L rides along for free.
+template <int WGM, int MI, bool VECA, bool VECB, bool DOT = false>
+__global__ __launch_bounds__(BG_THREADS, 2) void k_gemm_tn(long G, int M, int N, int lda, int ldb,
+                                                           const double *__restrict__ A, long strideA,
+                                                           const double *__restrict__ B, long strideB,
+                                                           long chunk, int nB, int npair, int split,
+                                                           double *__restrict__ C, int ldc, long strideC_batch,
+                                                           long strideC_chunk,
+                                                           const double *__restrict__ Dm = nullptr,
+                                                           double *__restrict__ vpart = nullptr)
+{
+    constexpr int BM = 64 * WGM, WGN = 8 / WGM, NJ = CD_BN / (16 * WGN); // NJ = 4 (WGM 2) or 2 (WGM 1)
+    constexpr int LDA_ = BM + 16;                                       // 144 / 80 = 16 (mod 32)
+    constexpr int ASZ = CD_BK * LDA_, BSZ = CD_BK * CD_LDB;
+    constexpr int AH = BM / 64; // double2 loads per thread for the A tile (16 rows x 32 groups)
+    __shared__ double lds[2 * (ASZ + BSZ)];
+    double *const As = lds, *const Bs = lds + 2 * ASZ;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int wm = wave / WGN, wn = wave % WGN;
+    int pair, ck;
+    long batch;
+    if (split) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pair = slot % npair;
+        ck = xcd + 8 * (slot / npair);
+        batch = 0;
+    } else {
+        pair = blockIdx.x % npair;
+        batch = blockIdx.x / npair;
+        ck = 0;
+    }
+    const int a0 = (pair / nB) * BM, b0 = (pair % nB) * CD_BN;
+    const long glo = (long)ck * chunk, ghi = min(G, glo + chunk);
+    A += batch * strideA;
+    B += batch * strideB;
+
+    d4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    if (glo < ghi) {
+        const int nst = (int)((ghi - glo + CD_BK - 1) / CD_BK);
+        const int s_row = tid >> 5, s_cq = tid & 31; // 16 rows x 32 column groups
+        const unsigned a_voff = (unsigned)(s_row * lda + a0 + 2 * AH * s_cq) * 8u;
+        const unsigned b_voff = (unsigned)(s_row * ldb + b0 + 8 * s_cq) * 8u;
+        double2 ra[AH], rb[4], rd[4];
+        double dot = 0.0;
+        const bool dot_on = DOT && a0 == 0; // uniform
+        auto fetch = [&](int st) {
+            const long row0 = glo + (long)st * CD_BK; // < ghi
+            const __amdgpu_buffer_rsrc_t da = plane_tile_rsrc(A, ghi * (long)lda, row0 * lda);
+            const __amdgpu_buffer_rsrc_t db = plane_tile_rsrc(B, ghi * (long)ldb, row0 * ldb);
+#pragma unroll
+            for (int h = 0; h < AH; ++h) ra[h] = buf_load_pair2<VECA>(da, a_voff + 16 * h, 0);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) rb[h] = buf_load_pair2<VECB>(db, b_voff + 16 * h, 0);
+            if (DOT) { // same rows / columns of the density matrix (ld = ldb = nao)
+                const __amdgpu_buffer_rsrc_t dd = plane_tile_rsrc(Dm, ghi * (long)ldb, row0 * ldb, dot_on);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) rd[h] = buf_load_pair2<VECB>(dd, b_voff + 16 * h, 0);
+            }
+        };
+        auto stash = [&](int buf) {
+            double *Ad = As + buf * ASZ + s_row * LDA_ + 2 * AH * s_cq;
+#pragma unroll
+            for (int h = 0; h < AH; ++h) *reinterpret_cast<double2 *>(Ad + 2 * h) = ra[h];
+            double *Bd = Bs + buf * BSZ + s_row * CD_LDB + 8 * s_cq;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) *reinterpret_cast<double2 *>(Bd + 2 * h) = rb[h];
+            if (DOT) {
+                const int col = b0 + 8 * s_cq; // columns past N hold the next row's data: masked out
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    dot += (col + 2 * h < N ? rb[h].x : 0.0) * rd[h].x;
+                    dot += (col + 2 * h + 1 < N ? rb[h].y : 0.0) * rd[h].y;
+                }
+            }
+        };
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nst) fetch(st + 1);
+            const double *Ap = As + buf * ASZ + lk * LDA_ + wm * 64 + li;
+            const double *Bp = Bs + buf * BSZ + lk * CD_LDB + wn * (16 * NJ) + li;
+#pragma unroll
+            for (int ks = 0; ks < CD_BK / 4; ++ks) {
+                double af[MI], bf[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = Ap[4 * ks * LDA_ + 16 * i];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bf[j] = Bp[4 * ks * CD_LDB + 16 * j];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+            }
+            if (st + 1 < nst) stash(buf ^ 1);
+            __syncthreads();
+        }
+        if (DOT && dot_on) { // fixed-order workgroup sum of the 512 partial dots (the tile LDS is free now)
+            lds[tid] = dot;
+            __syncthreads();
+            for (int w = BG_THREADS / 2; w > 0; w >>= 1) {
+                if (tid < w) lds[tid] += lds[tid + w];
+                __syncthreads();
+            }
+            if (tid == 0) vpart[batch * nB + pair % nB] = lds[0];
+        }
+    }
+
+    double *out = C + batch * strideC_batch + (long)ck * strideC_chunk;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int b = b0 + wn * (16 * NJ) + 16 * j + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = a0 + wm * 64 + 16 * i + lk + 4 * r;
+                if (a < M && b < N) out[(size_t)a * ldc + b] = acc[i][j][r];
+            }
+        }
+}
+
+// Cp[nu][i] = Cocc[nu][i] for i < nocc, 0 up to ldp (multiple of 16): aligned, zero-padded A operand
+__global__ __launch_bounds__(256) void k_pack_cocc(int nao, int nocc, int ldp, const double *__restrict__ c,
+                                                   double *__restrict__ cp)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)nao * ldp) return;
+    const int r = (int)(e / ldp), i = (int)(e % ldp);
+    cp[e] = i < nocc ? c[(size_t)r * nocc + i] : 0.0;
+}
+
+// v[P] = sum_e L[P][e] D[e]   (one workgroup per vector, fixed summation order)
+__global__ __launch_bounds__(256) void k_cd_dot(long n2, const double *__restrict__ L,
+                                                const double *__restrict__ D, double *__restrict__ v)
+{
+    __shared__ double red[256];
+    const double *Lp = L + (size_t)blockIdx.x * n2;
+    double s = 0.0;
+    for (long e = threadIdx.x; e < n2; e += 256) s += Lp[e] * D[e];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) v[blockIdx.x] = red[0];
+}
+
+// v[P] = sum_b vpart[P][b]: the per-b-block partials the half transform leaves (DOT), fixed order
+__global__ __launch_bounds__(256) void k_cd_vsum(int naux, int nB, const double *__restrict__ vpart,
+                                                 double *__restrict__ v)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= naux) return;
+    double s = 0.0;
+    for (int b = 0; b < nB; ++b) s += vpart[(size_t)p * nB + b];
+    v[p] = s;
+}
+
+// part[y][e] = sum_{P in slice y} v[P] L[P][e]; slices of `pslice` vectors, summed afterwards
+__global__ __launch_bounds__(256) void k_cd_axpy(long n2, int naux, int pslice, const double *__restrict__ L,
+                                                 const double *__restrict__ v, double *__restrict__ part)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n2) return;
+    const int p0 = blockIdx.y * pslice, p1 = min(naux, p0 + pslice);
+    double s = 0.0;
+#pragma unroll 4
+    for (int p = p0; p < p1; ++p) s += v[p] * L[(size_t)p * n2 + e];
+    part[(size_t)blockIdx.y * n2 + e] = s;
+}
+
+} // namespace qcdft

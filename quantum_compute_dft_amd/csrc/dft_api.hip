@@ -20,6 +20,7 @@
 #include "../../include/dft_solver.h"
 #include "ao_kernels.hpp"
 #include "jk_kernels.hpp"
+#include "cd_kernels.hpp"
 #include "xc_big_kernels.hpp"
 #include "xc_ws_kernels.hpp"
 #include "xc_kernels.hpp"
@@ -51,7 +52,7 @@ struct XCSolver {
     int profile = 0;
     int ksplit = 0;
     // workspace
-    DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells, msym;
+    DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells, msym, cdy, cdc, cdv;
     int spin_wait = 1; // poll the host-mapped Exc instead of sleeping in hipStreamSynchronize
     double *h_exc = nullptr;   // pinned, host-mapped: the reduce kernel writes Exc here
     double *h_exc_dev = nullptr; // device alias of h_exc
@@ -338,6 +339,113 @@ void jk(XCSolver *s, int nao, const double *eri, const double *dm, double *J, do
     hip_ok(s, hipGetLastError(), "J/K launch");
 }
 
+
+// chunks per XCD for a split-K launch of `npair` output tiles: the count (<= 32) whose workgroup
+// total fills whole rounds of the chip best, with slabs <= 2 GB and >= 64 contraction rows per chunk
+long chunks_per_xcd(const XCSolver *s, int npair, long rows, size_t slab_bytes)
+{
+    long per_xcd = 1;
+    double best = 0.0;
+    for (long c = 1; c <= 32; ++c) {
+        const long wgs = 8L * npair * c;
+        if (8 * c * 64 > rows && c > 1) break;
+        if ((double)(8 * c) * (double)slab_bytes > 2.0e9 && c > 1) break;
+        const long rounds = (wgs + s->num_cu - 1) / s->num_cu;
+        const double eff = (double)wgs / (double)(rounds * s->num_cu);
+        if (eff > best + 1e-9) { best = eff; per_xcd = c; }
+    }
+    return per_xcd;
+}
+
+// J and/or K from Cholesky vectors L (naux, nao, nao), D = dm, dm = cocc cocc^T with cocc (nao, nocc)
+int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, const double *dm,
+                  const double *cocc, double *J, double *K)
+{
+    s->last_error.clear();
+    if (!s->device_ok) { set_error(s, "no usable HIP device"); return -1; }
+    if (nao <= 0 || naux <= 0 || !L) { set_error(s, "factorised J/K: bad sizes nao=%d naux=%d", nao, naux); return -1; }
+    if (J && !dm) { set_error(s, "factorised J needs the density matrix"); return -1; }
+    if (K && (!cocc || nocc <= 0)) { set_error(s, "factorised K needs occupied orbitals (nocc=%d)", nocc); return -1; }
+    if (!J && !K) return 0;
+    hipStream_t st = s->stream;
+    const long n2 = (long)nao * nao;
+    const int nB = (nao + CD_BN - 1) / CD_BN;
+    // v_P = L_P : D.  With K wanted too, the half transform reads every L_P anyway and leaves the
+    // partial dots of its tiles (one per 256-column block); otherwise a pass of its own.
+    const bool fused_dot = J && K;
+    if (J) {
+        if (!reserve(s, s->cdv, sizeof(double) * (size_t)naux * (1 + nB), "hipMalloc(cd v)")) return -1;
+        if (!fused_dot) {
+            ScopedTimer t(s, "cd_dot");
+            hipLaunchKernelGGL(k_cd_dot, dim3((unsigned)naux), dim3(256), 0, st, n2, L, dm, (double *)s->cdv.p);
+        }
+    }
+    double *v = (double *)s->cdv.p, *vpart = v ? v + naux : nullptr;
+    if (K) {
+        const int ldp = ((nocc + 15) / 16) * 16;          // padded occupied dimension of the A operand
+        const int ldy = (nao + 1) & ~1;                   // even leading dimension of Yt: 16-byte rows
+        const long G = (long)naux * nocc;                 // rows of Yt
+        const int nA2 = (nao + 127) / 128, npair2 = nA2 * nB;
+        const long per_xcd = chunks_per_xcd(s, npair2, G, sizeof(double) * (size_t)n2);
+        const int nslab = (int)(8 * per_xcd);
+        long chunk = (G + nslab - 1) / nslab;
+        chunk = ((chunk + CD_BK - 1) / CD_BK) * CD_BK;
+        const bool fresh = sizeof(double) * (size_t)G * ldy > s->cdy.cap;
+        if (!reserve(s, s->cdc, sizeof(double) * (size_t)nao * ldp, "hipMalloc(cd cocc)") ||
+            !reserve(s, s->cdy, sizeof(double) * (size_t)G * ldy, "hipMalloc(cd Yt)") ||
+            !reserve(s, s->kpart, sizeof(double) * (size_t)nslab * n2, "hipMalloc(cd K slabs)"))
+            return -1;
+        double *cp = (double *)s->cdc.p, *yt = (double *)s->cdy.p, *kp = (double *)s->kpart.p;
+        if (fresh && ldy != nao) // the pad column is read (into discarded outputs) but never written
+            if (!hip_ok(s, hipMemsetAsync(yt, 0, s->cdy.cap, st), "memset(cd Yt)")) return -1;
+        const bool vecL = (nao % 2 == 0) && (((uintptr_t)L & 15) == 0) && (!fused_dot || ((uintptr_t)dm & 15) == 0);
+        {
+            ScopedTimer t(s, "cd_half");
+            hipLaunchKernelGGL(k_pack_cocc, dim3((unsigned)(((long)nao * ldp + 255) / 256)), dim3(256), 0, st, nao, nocc, ldp, cocc, cp);
+            // Yt_P (nocc x nao) = Cp^T L_P for every P
+#define QCDFT_HALF3(WGM, MI, VL, DOT)                                                                                 \
+    hipLaunchKernelGGL((k_gemm_tn<WGM, MI, true, VL, DOT>), g, dim3(BG_THREADS), 0, st, (long)nao, nocc, nao, ldp, nao, \
+                       cp, 0L, L, n2, (long)nao, nB, npair, 0, yt, ldy, (long)nocc * ldy, 0L, dm, vpart)
+#define QCDFT_HALF(WGM, MI)                                                                                           \
+    do {                                                                                                              \
+        const int nA = (nocc + 64 * WGM - 1) / (64 * WGM), npair = nA * nB;                                           \
+        dim3 g((unsigned)((long)npair * naux));                                                                       \
+        if (fused_dot) { if (vecL) QCDFT_HALF3(WGM, MI, true, true); else QCDFT_HALF3(WGM, MI, false, true); }        \
+        else           { if (vecL) QCDFT_HALF3(WGM, MI, true, false); else QCDFT_HALF3(WGM, MI, false, false); }      \
+    } while (0)
+            if (nocc <= 16) QCDFT_HALF(1, 1);
+            else if (nocc <= 32) QCDFT_HALF(1, 2);
+            else if (nocc <= 48) QCDFT_HALF(1, 3);
+            else if (nocc <= 64) QCDFT_HALF(1, 4);
+            else QCDFT_HALF(2, 4);
+#undef QCDFT_HALF
+#undef QCDFT_HALF3
+        }
+        {
+            ScopedTimer t(s, "cd_k");
+            // K = Yt^T Yt, split over the (P, i) rows
+            dim3 g((unsigned)(nslab * npair2));
+            hipLaunchKernelGGL((k_gemm_tn<2, 4, true, true>), g, dim3(BG_THREADS), 0, st, G, nao, nao, ldy, ldy,
+                               yt, 0L, yt, 0L, chunk, nB, npair2, 1, kp, nao, 0L, n2, (const double *)nullptr, (double *)nullptr);
+            hipLaunchKernelGGL(k_sum_slabs8, dim3((unsigned)((n2 + 31) / 32)), dim3(256), 0, st, (size_t)n2, nslab, (size_t)n2, kp, K);
+        }
+    }
+    if (J) {
+        ScopedTimer t(s, "cd_j");
+        // J = sum_P v_P L_P: slices of vectors so that the pass has >= ~4 workgroups per CU
+        const long eb = (n2 + 255) / 256;
+        int nsl = (int)std::max<long>(1, std::min<long>(naux, (4L * s->num_cu + eb - 1) / eb));
+        const int pslice = (naux + nsl - 1) / nsl;
+        nsl = (naux + pslice - 1) / pslice;
+        if (!reserve(s, s->jpart, sizeof(double) * (size_t)nsl * n2, "hipMalloc(cd J slabs)")) return -1;
+        double *jp = (double *)s->jpart.p;
+        if (fused_dot) hipLaunchKernelGGL(k_cd_vsum, dim3((unsigned)((naux + 255) / 256)), dim3(256), 0, st, naux, nB, vpart, v);
+        hipLaunchKernelGGL(k_cd_axpy, dim3((unsigned)eb, (unsigned)nsl), dim3(256), 0, st, n2, naux, pslice, L, v, jp);
+        hipLaunchKernelGGL(k_sum_slabs8, dim3((unsigned)((n2 + 31) / 32)), dim3(256), 0, st, (size_t)n2, nsl, (size_t)n2, jp, J);
+    }
+    return hip_ok(s, hipGetLastError(), "factorised J/K launch") ? 0 : -1;
+}
+
 } // namespace
 
 extern "C" {
@@ -379,7 +487,8 @@ void DFT_DestroySolver(XCSolver *s)
     if (s->device_ok) {
         (void)hipStreamSynchronize(s->stream);
         DevBuf *bufs[] = {&s->dsym, &s->rho, &s->sigma, &s->grad, &s->coef, &s->partial,
-                          &s->slabs, &s->exc, &s->jpart, &s->kpart, &s->shells, &s->msym};
+                          &s->slabs, &s->exc, &s->jpart, &s->kpart, &s->shells, &s->msym,
+                          &s->cdy, &s->cdc, &s->cdv};
         for (DevBuf *b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (s->h_exc) (void)hipHostFree(s->h_exc);
@@ -462,6 +571,16 @@ void DFT_ComputeJK(XCSolver *s, int nao, unsigned long long d_eri, unsigned long
 {
     if (!s) return;
     jk(s, nao, (const double *)d_eri, (const double *)d_dm, (double *)d_J, (double *)d_K);
+}
+
+int DFT_ComputeJKFactorized(XCSolver *s, int nao, int naux, int nocc, unsigned long long d_chol,
+                            unsigned long long d_dm, unsigned long long d_cocc, unsigned long long d_J,
+                            unsigned long long d_K)
+{
+    if (!s) return -1;
+    s->n_timed = 0;
+    return jk_factorized(s, nao, naux, nocc, (const double *)d_chol, (const double *)d_dm,
+                         (const double *)d_cocc, (double *)d_J, (double *)d_K);
 }
 
 int DFT_EvalAO(XCSolver *s, long long ngrid, int nao, int nshell, const double *shl_xyz,

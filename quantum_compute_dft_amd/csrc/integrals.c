@@ -258,96 +258,139 @@ static void rot_axis(int l, int n0, int n2, const double *in, double *out)
             }
 }
 
+/* Every shell pair A >= B with its primitive-pair data; shared by the dense and the column-wise
+ * (Cholesky) drivers. */
+typedef struct {
+    int nshell, nao, npairs;
+    const double *xyz, *ex, *cf;
+    const int *ls, *nprim, *off, *ao0;
+    int *pA, *pB;
+    PrimPair **pairs;
+    double *qmax; /* Schwarz bound sqrt(max (ab|ab)) per shell pair, filled by qc_eri_diag */
+    /* owned copies of the shell table (the context outlives the caller's arrays) */
+    double *own_xyz, *own_ex, *own_cf;
+    int *own_i;
+} EriCtx;
+
+static int pair_index(int A, int B) { return A >= B ? A * (A + 1) / 2 + B : B * (B + 1) / 2 + A; }
+
+static void ctx_build_pairs(EriCtx *c)
+{
+    const int nshell = c->nshell;
+    c->npairs = nshell * (nshell + 1) / 2;
+    c->pairs = (PrimPair **)calloc(c->npairs, sizeof(PrimPair *));
+    c->pA = (int *)malloc(sizeof(int) * c->npairs);
+    c->pB = (int *)malloc(sizeof(int) * c->npairs);
+    c->qmax = NULL;
+    for (int A = 0, k = 0; A < nshell; ++A)
+        for (int B = 0; B <= A; ++B, ++k) { c->pA[k] = A; c->pB[k] = B; }
+#pragma omp parallel for schedule(dynamic)
+    for (int k = 0; k < c->npairs; ++k) {
+        const int A = c->pA[k], B = c->pB[k];
+        c->pairs[k] = (PrimPair *)malloc(sizeof(PrimPair) * c->nprim[A] * c->nprim[B]);
+        for (int a = 0; a < c->nprim[A]; ++a)
+            for (int b = 0; b < c->nprim[B]; ++b)
+                make_pair(c->ls[A], c->ls[B], c->ex[c->off[A] + a], c->ex[c->off[B] + b], c->xyz + 3 * A,
+                          c->xyz + 3 * B, c->cf[c->off[A] + a] * c->cf[c->off[B] + b],
+                          &c->pairs[k][a * c->nprim[B] + b]);
+    }
+}
+
+static void ctx_free_pairs(EriCtx *c)
+{
+    for (int k = 0; k < c->npairs; ++k) free(c->pairs[k]);
+    free(c->pairs); free(c->pA); free(c->pB); free(c->qmax);
+}
+
+#define QUARTET_DOUBLES (MAXCART * MAXCART * MAXCART * MAXCART)
+
+/* (AB|CD) for shell pairs kab = (A >= B), kcd = (C >= D): spherical block [nsa][nsb][nsc][nsd] left
+ * in `cart` (t1 is scratch of the same size). */
+static void quartet(const EriCtx *c, int kab, int kcd, double *cart, double *t1, double R[RDIM][RDIM][RDIM])
+{
+    const int A = c->pA[kab], B = c->pB[kab], C = c->pA[kcd], D = c->pB[kcd];
+    const int *ls = c->ls, *nprim = c->nprim;
+    const int la = ls[A], lb = ls[B], lc = ls[C], ld = ls[D];
+    const int nca = NCART(la), ncb = NCART(lb), ncc = NCART(lc), ncd = NCART(ld);
+    int ax[MAXCART], ay[MAXCART], az[MAXCART], bx[MAXCART], by[MAXCART], bz[MAXCART];
+    int cx[MAXCART], cy[MAXCART], cz[MAXCART], dx[MAXCART], dy[MAXCART], dz[MAXCART];
+    cart_components(la, ax, ay, az); cart_components(lb, bx, by, bz);
+    cart_components(lc, cx, cy, cz); cart_components(ld, dx, dy, dz);
+    const int Lab = la + lb, Lcd = lc + ld, L = Lab + Lcd;
+    memset(cart, 0, sizeof(double) * nca * ncb * ncc * ncd);
+    const int nab = nprim[A] * nprim[B], ncdp = nprim[C] * nprim[D];
+    for (int iab = 0; iab < nab; ++iab) {
+        const PrimPair *ab = &c->pairs[kab][iab];
+        for (int icd = 0; icd < ncdp; ++icd) {
+            const PrimPair *cd = &c->pairs[kcd][icd];
+            const double p = ab->p, q = cd->p, alpha = p * q / (p + q);
+            const double PQ[3] = {ab->P[0] - cd->P[0], ab->P[1] - cd->P[1], ab->P[2] - cd->P[2]};
+            hermite_R(L, alpha, PQ, R);
+            const double pref = 2.0 * pow(M_PI, 2.5) / (p * q * sqrt(p + q)) * ab->cc * cd->cc;
+            /* g[t][u][v] = sum_{tau,nu,phi} (-1)^(tau+nu+phi) Ecd R[t+tau][u+nu][v+phi] per ket component */
+            for (int ic = 0; ic < ncc; ++ic)
+                for (int id = 0; id < ncd; ++id) {
+                    double g[HDIM][HDIM][HDIM];
+                    const int tx = cx[ic] + dx[id], ty = cy[ic] + dy[id], tz = cz[ic] + dz[id];
+                    for (int t = 0; t <= Lab; ++t)
+                        for (int u = 0; u <= Lab - t; ++u)
+                            for (int v = 0; v <= Lab - t - u; ++v) {
+                                double s = 0.0;
+                                for (int a1 = 0; a1 <= tx; ++a1) {
+                                    const double e1 = cd->E[0][cx[ic]][dx[id]][a1];
+                                    for (int a2 = 0; a2 <= ty; ++a2) {
+                                        const double e2 = e1 * cd->E[1][cy[ic]][dy[id]][a2];
+                                        for (int a3 = 0; a3 <= tz; ++a3) {
+                                            const double sg = ((a1 + a2 + a3) & 1) ? -1.0 : 1.0;
+                                            s += sg * e2 * cd->E[2][cz[ic]][dz[id]][a3] * R[t + a1][u + a2][v + a3];
+                                        }
+                                    }
+                                }
+                                g[t][u][v] = s;
+                            }
+                    for (int ia = 0; ia < nca; ++ia)
+                        for (int ib = 0; ib < ncb; ++ib) {
+                            double s = 0.0;
+                            for (int t = 0; t <= ax[ia] + bx[ib]; ++t) {
+                                const double e1 = ab->E[0][ax[ia]][bx[ib]][t];
+                                for (int u = 0; u <= ay[ia] + by[ib]; ++u) {
+                                    const double e2 = e1 * ab->E[1][ay[ia]][by[ib]][u];
+                                    for (int v = 0; v <= az[ia] + bz[ib]; ++v)
+                                        s += e2 * ab->E[2][az[ia]][bz[ib]][v] * g[t][u][v];
+                                }
+                            }
+                            cart[(((size_t)ia * ncb + ib) * ncc + ic) * ncd + id] += pref * s;
+                        }
+                }
+        }
+    }
+    /* Cartesian -> spherical on the four indices */
+    const int nsa = 2 * la + 1, nsb = 2 * lb + 1, nsc = 2 * lc + 1;
+    rot_axis(la, 1, ncb * ncc * ncd, cart, t1);
+    rot_axis(lb, nsa, ncc * ncd, t1, cart);
+    rot_axis(lc, nsa * nsb, ncd, cart, t1);
+    rot_axis(ld, nsa * nsb * nsc, 1, t1, cart);
+}
+
 int qc_int2e(int nshell, const double *xyz, const int *ls, const int *nprim, const int *off,
              const int *ao0, const double *ex, const double *cf, int nao, double *eri)
 {
     for (int s = 0; s < nshell; ++s)
         if (ls[s] < 0 || ls[s] > LMAX) return -1;
     const size_t n = (size_t)nao;
-    const int npairs = nshell * (nshell + 1) / 2;
-    /* primitive-pair data of every shell pair A >= B */
-    PrimPair **pairs = (PrimPair **)calloc(npairs, sizeof(PrimPair *));
-    int *pA = (int *)malloc(sizeof(int) * npairs), *pB = (int *)malloc(sizeof(int) * npairs);
-    for (int A = 0, k = 0; A < nshell; ++A)
-        for (int B = 0; B <= A; ++B, ++k) { pA[k] = A; pB[k] = B; }
-#pragma omp parallel for schedule(dynamic)
-    for (int k = 0; k < npairs; ++k) {
-        const int A = pA[k], B = pB[k];
-        pairs[k] = (PrimPair *)malloc(sizeof(PrimPair) * nprim[A] * nprim[B]);
-        for (int a = 0; a < nprim[A]; ++a)
-            for (int b = 0; b < nprim[B]; ++b)
-                make_pair(ls[A], ls[B], ex[off[A] + a], ex[off[B] + b], xyz + 3 * A, xyz + 3 * B,
-                          cf[off[A] + a] * cf[off[B] + b], &pairs[k][a * nprim[B] + b]);
-    }
+    EriCtx ctx = {nshell, nao, 0, xyz, ex, cf, ls, nprim, off, ao0};
+    ctx_build_pairs(&ctx);
 #pragma omp parallel
     {
-        double *cart = (double *)malloc(sizeof(double) * MAXCART * MAXCART * MAXCART * MAXCART);
-        double *t1 = (double *)malloc(sizeof(double) * MAXCART * MAXCART * MAXCART * MAXCART);
+        double *cart = (double *)malloc(sizeof(double) * QUARTET_DOUBLES);
+        double *t1 = (double *)malloc(sizeof(double) * QUARTET_DOUBLES);
         static _Thread_local double R[RDIM][RDIM][RDIM];
 #pragma omp for schedule(dynamic)
-        for (int kab = 0; kab < npairs; ++kab)
+        for (int kab = 0; kab < ctx.npairs; ++kab)
             for (int kcd = 0; kcd <= kab; ++kcd) {
-                const int A = pA[kab], B = pB[kab], C = pA[kcd], D = pB[kcd];
-                const int la = ls[A], lb = ls[B], lc = ls[C], ld = ls[D];
-                const int nca = NCART(la), ncb = NCART(lb), ncc = NCART(lc), ncd = NCART(ld);
-                int ax[MAXCART], ay[MAXCART], az[MAXCART], bx[MAXCART], by[MAXCART], bz[MAXCART];
-                int cx[MAXCART], cy[MAXCART], cz[MAXCART], dx[MAXCART], dy[MAXCART], dz[MAXCART];
-                cart_components(la, ax, ay, az); cart_components(lb, bx, by, bz);
-                cart_components(lc, cx, cy, cz); cart_components(ld, dx, dy, dz);
-                const int Lab = la + lb, Lcd = lc + ld, L = Lab + Lcd;
-                memset(cart, 0, sizeof(double) * nca * ncb * ncc * ncd);
-                const int nab = nprim[A] * nprim[B], ncdp = nprim[C] * nprim[D];
-                for (int iab = 0; iab < nab; ++iab) {
-                    const PrimPair *ab = &pairs[kab][iab];
-                    for (int icd = 0; icd < ncdp; ++icd) {
-                        const PrimPair *cd = &pairs[kcd][icd];
-                        const double p = ab->p, q = cd->p, alpha = p * q / (p + q);
-                        const double PQ[3] = {ab->P[0] - cd->P[0], ab->P[1] - cd->P[1], ab->P[2] - cd->P[2]};
-                        hermite_R(L, alpha, PQ, R);
-                        const double pref = 2.0 * pow(M_PI, 2.5) / (p * q * sqrt(p + q)) * ab->cc * cd->cc;
-                        /* g[t][u][v] = sum_{tau,nu,phi} (-1)^(tau+nu+phi) Ecd R[t+tau][u+nu][v+phi] per ket component */
-                        for (int ic = 0; ic < ncc; ++ic)
-                            for (int id = 0; id < ncd; ++id) {
-                                double g[HDIM][HDIM][HDIM];
-                                const int tx = cx[ic] + dx[id], ty = cy[ic] + dy[id], tz = cz[ic] + dz[id];
-                                for (int t = 0; t <= Lab; ++t)
-                                    for (int u = 0; u <= Lab - t; ++u)
-                                        for (int v = 0; v <= Lab - t - u; ++v) {
-                                            double s = 0.0;
-                                            for (int a1 = 0; a1 <= tx; ++a1) {
-                                                const double e1 = cd->E[0][cx[ic]][dx[id]][a1];
-                                                for (int a2 = 0; a2 <= ty; ++a2) {
-                                                    const double e2 = e1 * cd->E[1][cy[ic]][dy[id]][a2];
-                                                    for (int a3 = 0; a3 <= tz; ++a3) {
-                                                        const double sg = ((a1 + a2 + a3) & 1) ? -1.0 : 1.0;
-                                                        s += sg * e2 * cd->E[2][cz[ic]][dz[id]][a3] * R[t + a1][u + a2][v + a3];
-                                                    }
-                                                }
-                                            }
-                                            g[t][u][v] = s;
-                                        }
-                                for (int ia = 0; ia < nca; ++ia)
-                                    for (int ib = 0; ib < ncb; ++ib) {
-                                        double s = 0.0;
-                                        for (int t = 0; t <= ax[ia] + bx[ib]; ++t) {
-                                            const double e1 = ab->E[0][ax[ia]][bx[ib]][t];
-                                            for (int u = 0; u <= ay[ia] + by[ib]; ++u) {
-                                                const double e2 = e1 * ab->E[1][ay[ia]][by[ib]][u];
-                                                for (int v = 0; v <= az[ia] + bz[ib]; ++v)
-                                                    s += e2 * ab->E[2][az[ia]][bz[ib]][v] * g[t][u][v];
-                                            }
-                                        }
-                                        cart[(((size_t)ia * ncb + ib) * ncc + ic) * ncd + id] += pref * s;
-                                    }
-                            }
-                    }
-                }
-                /* Cartesian -> spherical on the four indices */
-                const int nsa = 2 * la + 1, nsb = 2 * lb + 1, nsc = 2 * lc + 1, nsd = 2 * ld + 1;
-                rot_axis(la, 1, ncb * ncc * ncd, cart, t1);
-                rot_axis(lb, nsa, ncc * ncd, t1, cart);
-                rot_axis(lc, nsa * nsb, ncd, cart, t1);
-                rot_axis(ld, nsa * nsb * nsc, 1, t1, cart);
+                const int A = ctx.pA[kab], B = ctx.pB[kab], C = ctx.pA[kcd], D = ctx.pB[kcd];
+                const int nsa = 2 * ls[A] + 1, nsb = 2 * ls[B] + 1, nsc = 2 * ls[C] + 1, nsd = 2 * ls[D] + 1;
+                quartet(&ctx, kab, kcd, cart, t1, R);
                 /* scatter with the 8-fold permutational symmetry */
                 for (int a = 0; a < nsa; ++a)
                     for (int b = 0; b < nsb; ++b)
@@ -368,7 +411,117 @@ int qc_int2e(int nshell, const double *xyz, const int *ls, const int *nprim, con
         free(cart);
         free(t1);
     }
-    for (int k = 0; k < npairs; ++k) free(pairs[k]);
-    free(pairs); free(pA); free(pB);
+    ctx_free_pairs(&ctx);
+    return 0;
+}
+
+/* ---- column-wise access for the pivoted Cholesky factorisation (no dense ERI) ------------------- */
+void *qc_eri_open(int nshell, const double *xyz, const int *ls, const int *nprim, const int *off,
+                  const int *ao0, const double *ex, const double *cf, int nao, int nprim_total)
+{
+    for (int s = 0; s < nshell; ++s)
+        if (ls[s] < 0 || ls[s] > LMAX) return NULL;
+    EriCtx *c = (EriCtx *)calloc(1, sizeof(EriCtx));
+    c->nshell = nshell; c->nao = nao;
+    c->own_xyz = (double *)malloc(sizeof(double) * 3 * nshell);
+    c->own_ex = (double *)malloc(sizeof(double) * nprim_total);
+    c->own_cf = (double *)malloc(sizeof(double) * nprim_total);
+    c->own_i = (int *)malloc(sizeof(int) * 4 * nshell);
+    memcpy(c->own_xyz, xyz, sizeof(double) * 3 * nshell);
+    memcpy(c->own_ex, ex, sizeof(double) * nprim_total);
+    memcpy(c->own_cf, cf, sizeof(double) * nprim_total);
+    memcpy(c->own_i, ls, sizeof(int) * nshell);
+    memcpy(c->own_i + nshell, nprim, sizeof(int) * nshell);
+    memcpy(c->own_i + 2 * nshell, off, sizeof(int) * nshell);
+    memcpy(c->own_i + 3 * nshell, ao0, sizeof(int) * nshell);
+    c->xyz = c->own_xyz; c->ex = c->own_ex; c->cf = c->own_cf;
+    c->ls = c->own_i; c->nprim = c->own_i + nshell; c->off = c->own_i + 2 * nshell; c->ao0 = c->own_i + 3 * nshell;
+    ctx_build_pairs(c);
+    return c;
+}
+
+void qc_eri_close(void *h)
+{
+    EriCtx *c = (EriCtx *)h;
+    if (!c) return;
+    ctx_free_pairs(c);
+    free(c->own_xyz); free(c->own_ex); free(c->own_cf); free(c->own_i);
+    free(c);
+}
+
+/* diag[i*nao + j] = (ij|ij); also records the Schwarz bounds used to skip quartets in qc_eri_cols */
+int qc_eri_diag(void *h, double *diag)
+{
+    EriCtx *c = (EriCtx *)h;
+    if (!c) return -1;
+    const size_t n = (size_t)c->nao;
+    if (!c->qmax) c->qmax = (double *)malloc(sizeof(double) * c->npairs);
+#pragma omp parallel
+    {
+        double *cart = (double *)malloc(sizeof(double) * QUARTET_DOUBLES);
+        double *t1 = (double *)malloc(sizeof(double) * QUARTET_DOUBLES);
+        static _Thread_local double R[RDIM][RDIM][RDIM];
+#pragma omp for schedule(dynamic)
+        for (int kab = 0; kab < c->npairs; ++kab) {
+            const int A = c->pA[kab], B = c->pB[kab];
+            const int nsa = 2 * c->ls[A] + 1, nsb = 2 * c->ls[B] + 1;
+            quartet(c, kab, kab, cart, t1, R);
+            double m = 0.0;
+            for (int a = 0; a < nsa; ++a)
+                for (int b = 0; b < nsb; ++b) {
+                    const double v = cart[(((size_t)a * nsb + b) * nsa + a) * nsb + b];
+                    const size_t i = c->ao0[A] + a, j = c->ao0[B] + b;
+                    diag[i * n + j] = v;
+                    diag[j * n + i] = v;
+                    if (v > m) m = v;
+                }
+            c->qmax[kab] = sqrt(m);
+        }
+        free(cart);
+        free(t1);
+    }
+    return 0;
+}
+
+/* All integrals (ij|kl) with k in shell C, l in shell D: out[(k_local*nsd + l_local)][i][j], each an
+ * (nao,nao) symmetric matrix.  Quartets below the Schwarz bound `screen` are left zero.
+ * qc_eri_diag must have been called. */
+int qc_eri_cols(void *h, int C, int D, double screen, double *out)
+{
+    EriCtx *c = (EriCtx *)h;
+    if (!c || !c->qmax || C < 0 || D < 0 || C >= c->nshell || D >= c->nshell) return -1;
+    const size_t n = (size_t)c->nao;
+    const int kcd = pair_index(C, D);
+    const int swap = C < D; /* stored pair is (max, min) */
+    const int nsc = 2 * c->ls[C] + 1, nsd = 2 * c->ls[D] + 1;
+    memset(out, 0, sizeof(double) * n * n * nsc * nsd);
+#pragma omp parallel
+    {
+        double *cart = (double *)malloc(sizeof(double) * QUARTET_DOUBLES);
+        double *t1 = (double *)malloc(sizeof(double) * QUARTET_DOUBLES);
+        static _Thread_local double R[RDIM][RDIM][RDIM];
+#pragma omp for schedule(dynamic)
+        for (int kab = 0; kab < c->npairs; ++kab) {
+            if (c->qmax[kab] * c->qmax[kcd] < screen) continue;
+            const int A = c->pA[kab], B = c->pB[kab];
+            const int nsa = 2 * c->ls[A] + 1, nsb = 2 * c->ls[B] + 1;
+            quartet(c, kab, kcd, cart, t1, R);
+            /* block is [a][b][c'][d'] with (c',d') over the stored (max,min) shells */
+            const int n3 = swap ? nsd : nsc, n4 = swap ? nsc : nsd;
+            for (int a = 0; a < nsa; ++a)
+                for (int b = 0; b < nsb; ++b)
+                    for (int k = 0; k < nsc; ++k)
+                        for (int l = 0; l < nsd; ++l) {
+                            const int c3 = swap ? l : k, c4 = swap ? k : l;
+                            const double v = cart[(((size_t)a * nsb + b) * n3 + c3) * n4 + c4];
+                            const size_t i = c->ao0[A] + a, j = c->ao0[B] + b;
+                            double *m = out + (size_t)(k * nsd + l) * n * n;
+                            m[i * n + j] = v;
+                            m[j * n + i] = v;
+                        }
+        }
+        free(cart);
+        free(t1);
+    }
     return 0;
 }

@@ -237,7 +237,6 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_vxc_big(long ngrid, int nao, 
     const int pair = slot % npair, ck = xcd + 8 * (slot / npair);
     const int a0 = (pair / nB) * BG_BM, b0 = (pair % nB) * BG_BN;
     const long glo = (long)ck * chunk, ghi = min(ngrid, glo + chunk);
-    const long plane = ngrid * (long)nao;
 
     d4 acc[4][4];
 #pragma unroll

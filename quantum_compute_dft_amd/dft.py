@@ -18,6 +18,9 @@ def main(argv=None):
     p.add_argument("--grid-level", type=int, default=3)   # grid.py:59
     p.add_argument("--quirks", type=int, default=1, help="1: reference formulas as shipped; 0: corrected VWN5/PBE-c derivatives")
     p.add_argument("--lib", default=None, help="path of libdft.so")
+    p.add_argument("--eri", default="dense", choices=["dense", "cholesky"],
+                   help="dense: the nao^4 tensor of grid.py:65; cholesky: factorised J/K (large basis sets)")
+    p.add_argument("--chol-tol", type=float, default=1e-9)
     args = p.parse_args(argv)
 
     atom_file = args.xyzfile if args.xyzfile.lower().endswith(".xyz") else args.xyzfile + ".xyz"
@@ -27,7 +30,7 @@ def main(argv=None):
         sys.exit(1)
     print(f"=== DFT Solver: {args.functional} | Molecule: {atom_file} ===")
     print("Building CPU data...")
-    inp = inputs.build(atom_path, args.basis, args.grid_level, device="cuda")
+    inp = inputs.build(atom_path, args.basis, args.grid_level, device="cuda", eri_mode=args.eri, chol_tol=args.chol_tol)
     print(f"System Info: NAO={inp.shells.nao}, Grid={inp.grids.size}, Occupied={inp.nocc}")
     print(f"Calculating AO Gradients ({args.functional} mode)..." if args.functional != "LDA" else "Skipping AO Gradients (LDA mode).")
     print("Moving data to GPU...")

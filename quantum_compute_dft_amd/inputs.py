@@ -22,14 +22,17 @@ class SCFInputs:
     T: np.ndarray
     V: np.ndarray
     Hcore: np.ndarray
-    eri: np.ndarray        # (nao, nao, nao, nao)
+    eri: np.ndarray        # (nao, nao, nao, nao), or None when only Cholesky vectors were built
     E_nuc: float
     nocc: int
     nelec: int
+    chol: np.ndarray = None  # (naux, nao, nao) Cholesky vectors of the ERI (eri_mode='cholesky')
 
 
-def build(atom_path, basis_name="sto-3g", grid_level=3, device="cpu", verbose=True):
-    """grid.py:42-67.  `atom_path`: an .xyz file (or a molecule name resolved in data/)."""
+def build(atom_path, basis_name="sto-3g", grid_level=3, device="cpu", verbose=True, eri_mode="dense",
+          chol_tol=1e-9):
+    """grid.py:42-67.  `atom_path`: an .xyz file (or a molecule name resolved in data/).
+    eri_mode "dense": the (nao^4) tensor of grid.py:65; "cholesky": pivoted Cholesky vectors only."""
     if not os.path.exists(atom_path):
         cand = os.path.join(DATA_DIR, atom_path if atom_path.endswith(".xyz") else atom_path + ".xyz")
         if os.path.exists(cand):
@@ -48,6 +51,15 @@ def build(atom_path, basis_name="sto-3g", grid_level=3, device="cpu", verbose=Tr
     if verbose:
         print(f"Number of grid points for integration: {grids.size}")
     S, T, V = integrals.int1e(shells, symbols, xyz)
-    eri = integrals.int2e(shells)
+    eri = chol = None
+    if eri_mode == "dense":
+        eri = integrals.int2e(shells)
+    elif eri_mode == "cholesky":
+        from .cholesky import cholesky_eri
+        chol = cholesky_eri(shells, tol=chol_tol)
+        if verbose:
+            print(f"Cholesky vectors of the ERI: {chol.shape[0]} (threshold {chol_tol:g})")
+    else:
+        raise ValueError(f"eri_mode {eri_mode!r}: expected 'dense' or 'cholesky'")
     return SCFInputs(symbols, xyz, shells, grids, S, T, V, T + V, eri,
-                     integrals.energy_nuc(symbols, xyz), nocc, nelec)
+                     integrals.energy_nuc(symbols, xyz), nocc, nelec, chol)

@@ -35,6 +35,14 @@ def _load():
         L.qc_int1e.argtypes = [ctypes.c_int, dp, ip, ip, ip, ip, dp, dp, ctypes.c_int, ctypes.c_int, dp, dp, dp, dp, dp]
         L.qc_int2e.restype = ctypes.c_int
         L.qc_int2e.argtypes = [ctypes.c_int, dp, ip, ip, ip, ip, dp, dp, ctypes.c_int, dp]
+        L.qc_eri_open.restype = ctypes.c_void_p
+        L.qc_eri_open.argtypes = [ctypes.c_int, dp, ip, ip, ip, ip, dp, dp, ctypes.c_int, ctypes.c_int]
+        L.qc_eri_close.restype = None
+        L.qc_eri_close.argtypes = [ctypes.c_void_p]
+        L.qc_eri_diag.restype = ctypes.c_int
+        L.qc_eri_diag.argtypes = [ctypes.c_void_p, dp]
+        L.qc_eri_cols.restype = ctypes.c_int
+        L.qc_eri_cols.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, dp]
         _lib = L
     return _lib
 
@@ -83,3 +91,37 @@ def energy_nuc(symbols, atom_xyz):
         for j in range(i):
             e += z[i] * z[j] / np.linalg.norm(xyz[i] - xyz[j])
     return e
+
+
+class EriColumns:
+    """Column-wise access to the ERI without the dense tensor (for the pivoted Cholesky
+    factorisation of cholesky.py): `diag()` = (ij|ij), `cols(C, D)` = every (ij|kl) with k in shell
+    C and l in shell D."""
+
+    def __init__(self, shells):
+        keep, p = _args(shells)
+        self.shells, self.nao = shells, shells.nao
+        self._h = _load().qc_eri_open(shells.nshell, *p, shells.nao, len(shells.exp))
+        if not self._h:
+            raise ValueError("integrals: angular momentum above f is not supported")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _load().qc_eri_close(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def diag(self):
+        d = np.zeros((self.nao, self.nao))
+        _load().qc_eri_diag(self._h, d.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        return d
+
+    def cols(self, C, D, screen=1e-14):
+        """(nfC*nfD, nao, nao): entry [k*nfD + l] is the symmetric matrix (..|kl)."""
+        nf = (2 * int(self.shells.l[C]) + 1) * (2 * int(self.shells.l[D]) + 1)
+        out = np.empty((nf, self.nao, self.nao))
+        rc = _load().qc_eri_cols(self._h, int(C), int(D), float(screen), out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        if rc != 0:
+            raise RuntimeError("qc_eri_cols failed (diag() must be called first)")
+        return out

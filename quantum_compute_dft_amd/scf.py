@@ -59,7 +59,13 @@ class HipBackend:
         self.d_ao = torch.empty((ngrid, nao), dtype=f64, device=self.dev)
         self.d_gr = torch.empty((3, ngrid, nao), dtype=f64, device=self.dev) if self.functional != "LDA" else None
         self.solver.eval_ao(inp.shells, d_coords, ngrid, self.d_ao, self.d_gr)      # grid.py:30,38 on the device
-        self.d_eri = torch.as_tensor(inp.eri.reshape(nao * nao, nao * nao), dtype=f64, device=self.dev)  # dft.py:166
+        self.d_eri = self.d_chol = self.d_cocc = None
+        if inp.eri is not None:
+            self.d_eri = torch.as_tensor(inp.eri.reshape(nao * nao, nao * nao), dtype=f64, device=self.dev)  # dft.py:166
+        else:  # factorised J/K (DFT_ComputeJKFactorized): Cholesky vectors stay resident instead of the ERI
+            self.d_chol = torch.as_tensor(inp.chol, dtype=f64, device=self.dev)
+            self.d_cocc = torch.zeros((nao, inp.nocc), dtype=f64, device=self.dev)
+        self.nocc = inp.nocc
         self.d_dm = torch.zeros((nao, nao), dtype=f64, device=self.dev)
         self.d_J = torch.zeros_like(self.d_dm); self.d_K = torch.zeros_like(self.d_dm); self.d_v = torch.zeros_like(self.d_dm)
         torch.cuda.synchronize()
@@ -68,7 +74,16 @@ class HipBackend:
     def set_dm(self, dm):
         self.d_dm.copy_(self.torch.as_tensor(dm, dtype=self.torch.float64))       # dft.py:200
 
+    def set_cocc(self, cocc):
+        """cocc (nao, nocc) with dm = cocc cocc^T; only the factorised exchange needs it."""
+        if self.d_cocc is not None:
+            self.d_cocc.copy_(self.torch.as_tensor(np.ascontiguousarray(cocc), dtype=self.torch.float64))
+
     def jk(self, want_k):
+        if self.d_chol is not None:
+            self.solver.compute_jk_factorized(self.nao, self.d_chol.shape[0], self.nocc, self.d_chol, self.d_dm,
+                                              self.d_cocc if want_k else None, self.d_J, self.d_K if want_k else None)
+            return self.d_J.cpu().numpy(), (self.d_K.cpu().numpy() if want_k else None)
         if want_k:
             self.solver.compute_jk(self.nao, self.d_eri, self.d_dm, self.d_J, self.d_K)
             return self.d_J.cpu().numpy(), self.d_K.cpu().numpy()
@@ -88,6 +103,7 @@ def run_scf(inp, backend, functional, max_cycle=200, conv_e=1e-8, conv_dm=1e-6, 
     Hcore, S, nocc = inp.Hcore, inp.S, inp.nocc
     e, C = eigh(Hcore, S)                                                              # dft.py:181
     dm = 2.0 * C[:, :nocc] @ C[:, :nocc].T
+    set_cocc = getattr(backend, "set_cocc", None)
     diis = CDIIS()
     if log:
         log("\nSCF started!"); log("-" * 80)
@@ -96,6 +112,8 @@ def run_scf(inp, backend, functional, max_cycle=200, conv_e=1e-8, conv_dm=1e-6, 
     res = {"converged": False}
     for cycle in range(max_cycle):
         backend.set_dm(dm)
+        if set_cocc:
+            set_cocc(np.sqrt(2.0) * C[:, :nocc])
         J, K = backend.jk(functional == "B3LYP")
         E_xc, Vraw, t_xc = backend.xc()
         xc_times.append(t_xc)

@@ -70,6 +70,9 @@ class DFTSolverWrapper:
         L.DFT_ComputeExchange.restype = None
         L.DFT_ComputeJK.argtypes = [ctypes.c_void_p, ctypes.c_int, _u64, _u64, _u64, _u64]
         L.DFT_ComputeJK.restype = None
+        L.DFT_ComputeJKFactorized.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              _u64, _u64, _u64, _u64, _u64]
+        L.DFT_ComputeJKFactorized.restype = ctypes.c_int
         dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
         L.DFT_EvalAO.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
                                  dp, ip, ip, ip, ip, dp, dp, ctypes.c_int, _u64, _u64, _u64]
@@ -134,6 +137,14 @@ class DFTSolverWrapper:
         self.lib.DFT_ComputeJK(self.solver, int(nao), _u64(_ptr(d_eri)), _u64(_ptr(d_dm)),
                                _u64(_ptr(d_J)), _u64(_ptr(d_K)))
         self._check()
+
+    def compute_jk_factorized(self, nao, naux, nocc, d_chol, d_dm, d_cocc, d_J, d_K):
+        """J, K from Cholesky vectors d_chol (naux, nao, nao); dm = cocc cocc^T, cocc (nao, nocc).
+        d_J / d_K (and the input only the other one needs) may be None."""
+        rc = self.lib.DFT_ComputeJKFactorized(self.solver, int(nao), int(naux), int(nocc), _u64(_ptr(d_chol)),
+                                              _u64(_ptr(d_dm)), _u64(_ptr(d_cocc)), _u64(_ptr(d_J)), _u64(_ptr(d_K)))
+        self._check()
+        return rc
 
     def eval_ao(self, shells, d_coords, ngrid, d_ao, d_ao_grad=None):
         """shells: a basis.ShellTable (host numpy arrays, see basis.py)."""

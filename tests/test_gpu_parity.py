@@ -308,6 +308,87 @@ def test_full_scf_matches_the_oracle_driven_scf(dev, fn, bname):
     assert np.abs(r_gpu["dm"] - r_cpu["dm"]).max() < 1e-7
 
 
+def _factor_case(nao, naux, nocc, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.normal(0, 0.3, (naux, nao, nao))
+    chol = 0.5 * (A + A.transpose(0, 2, 1))
+    cocc = rng.normal(0, 0.7, (nao, nocc))
+    return chol, cocc, cocc @ cocc.T
+
+
+@pytest.mark.parametrize("nao,naux,nocc", [
+    (24, 181, 5),      # H2O/def2-SVP sizes
+    (37, 50, 16),      # odd nao: 8-byte loads of L, padded Yt rows
+    (114, 300, 21),    # Benzene/def2-SVP
+    (130, 64, 40),     # one row tile, two occupied tiles of 16 unused
+    (150, 33, 70),     # nocc > 64: 128-row tiles in the half transform
+    (262, 40, 9),      # two column blocks
+    (16, 1, 1),
+])
+def test_factorised_jk_matches_numpy_restatement(dev, nao, naux, nocc):
+    """DFT_ComputeJKFactorized against the oracle's J = sum (L:D) L, K = sum L D L from the same factors."""
+    chol, cocc, dm = _factor_case(nao, naux, nocc, 100 + nao)
+    J_ref, K_ref = oracle.jk_from_factors(chol, dm)
+    w = _solver(2)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    d_L, d_dm, d_c = t(chol), t(dm), t(cocc)
+    d_J = torch.full((nao, nao), 7.0, dtype=torch.float64, device=dev); d_K = torch.full_like(d_J, 7.0)
+    assert w.compute_jk_factorized(nao, naux, nocc, d_L, d_dm, d_c, d_J, d_K) == 0
+    torch.cuda.synchronize()
+    assert np.abs(d_J.cpu().numpy() - J_ref).max() <= 1e-12 * np.abs(J_ref).max()
+    assert np.abs(d_K.cpu().numpy() - K_ref).max() <= 1e-12 * np.abs(K_ref).max()
+    # either output alone (J then takes its own pass for L:D instead of the one fused into the half
+    # transform: same value, different summation order; K is bit-identical), and deterministic
+    d_J2 = torch.zeros_like(d_J); d_K2 = torch.zeros_like(d_K); d_J3 = torch.zeros_like(d_J); d_K3 = torch.zeros_like(d_K)
+    assert w.compute_jk_factorized(nao, naux, nocc, d_L, d_dm, None, d_J2, None) == 0
+    assert w.compute_jk_factorized(nao, naux, nocc, d_L, None, d_c, None, d_K2) == 0
+    assert w.compute_jk_factorized(nao, naux, nocc, d_L, d_dm, d_c, d_J3, d_K3) == 0
+    torch.cuda.synchronize()
+    assert np.abs(d_J2.cpu().numpy() - J_ref).max() <= 1e-12 * np.abs(J_ref).max()
+    assert torch.equal(d_K2, d_K) and torch.equal(d_J3, d_J) and torch.equal(d_K3, d_K)
+    with pytest.raises(RuntimeError):
+        w.compute_jk_factorized(nao, naux, 0, d_L, d_dm, None, None, d_K2)   # K without orbitals
+
+
+@pytest.mark.parametrize("bname,tol", [("sto-3g", 1e-10), ("def2-svp", 1e-9)])
+def test_factorised_jk_matches_dense_eri_oracle(dev, bname, tol):
+    """Cholesky vectors of the real H2O ERI: J, K agree with the reference's dense contractions
+    (dft_solver.cu:550-555, dft.py:218 via the oracle) to the factorisation threshold."""
+    from quantum_compute_dft_amd import integrals
+    from quantum_compute_dft_amd.cholesky import cholesky_eri
+    syms, xyz = basis.parse_xyz("O 0 0 0.1173; H 0 0.7572 -0.4692; H 0 -0.7572 -0.4692")
+    sh = basis.build_shells(syms, xyz, bname)
+    eri = integrals.int2e(sh)
+    chol = cholesky_eri(sh, tol=tol)
+    n, nocc = sh.nao, 5
+    rng = np.random.default_rng(3)
+    cocc = rng.normal(0, 0.5, (n, nocc))
+    dm = cocc @ cocc.T
+    J_ref, K_ref = oracle.coulomb(eri, dm), oracle.exchange(eri, dm)
+    w = _solver(2)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    d_J = torch.zeros((n, n), dtype=torch.float64, device=dev); d_K = torch.zeros_like(d_J)
+    assert w.compute_jk_factorized(n, chol.shape[0], nocc, t(chol), t(dm), t(cocc), d_J, d_K) == 0
+    torch.cuda.synchronize()
+    bound = tol * np.abs(dm).sum()     # |sum_kl R_ijkl D_kl| <= max|R| * sum|D|
+    assert np.abs(d_J.cpu().numpy() - J_ref).max() <= bound
+    assert np.abs(d_K.cpu().numpy() - K_ref).max() <= bound
+
+
+@pytest.mark.parametrize("fn", ["LDA", "B3LYP"])
+def test_scf_with_factorised_jk_matches_dense_scf(dev, fn):
+    from quantum_compute_dft_amd import inputs, scf
+    kw = dict(log=None, conv_e=1e-11, conv_dm=1e-9)
+    dense = inputs.build("H2O", "def2-svp", 3, verbose=False)
+    fact = inputs.build("H2O", "def2-svp", 3, verbose=False, eri_mode="cholesky", chol_tol=1e-10)
+    assert fact.eri is None and fact.chol.shape[1:] == (24, 24)
+    r_d = scf.run_scf(dense, scf.HipBackend(dense, fn), fn, **kw)
+    r_f = scf.run_scf(fact, scf.HipBackend(fact, fn), fn, **kw)
+    assert r_d["converged"] and r_f["converged"]
+    assert r_f["E_tot"] == pytest.approx(r_d["E_tot"], abs=2e-8)
+    assert r_f["E_ex_hf"] == pytest.approx(r_d["E_ex_hf"], abs=2e-8)
+
+
 def test_more_than_2_31_ao_elements(dev):
     """ngrid*nao = 2.4e9 > 2^31 (the reference's int products overflow at 2^30, dft_solver.cu:597,634).
     The AO array is a small block repeated R times, so Exc and V must be exactly R x the block's

@@ -87,3 +87,26 @@ def test_water_sto3g_rhf_energy_is_sane():
     S, T, V = integrals.int1e(sh, syms, xyz)
     E = _rhf(S, T + V, integrals.int2e(sh), 5, integrals.energy_nuc(syms, xyz))
     assert -74.98 < E < -74.94
+
+
+def test_pivoted_cholesky_reproduces_the_dense_eri():
+    """Integral-direct pivoted Cholesky (cholesky.py): residual below the threshold everywhere,
+    symmetric vectors, rank grows with the threshold; column access equals slices of the tensor."""
+    from quantum_compute_dft_amd.cholesky import cholesky_eri
+    syms, xyz = basis.parse_xyz("O 0 0 0.1173; H 0 0.7572 -0.4692; H 0 -0.7572 -0.4692")
+    sh = basis.build_shells(syms, xyz, "def2-svp")
+    eri = integrals.int2e(sh)
+    n = sh.nao
+    cols = integrals.EriColumns(sh)
+    assert np.abs(cols.diag() - np.einsum("ijij->ij", eri)).max() < 1e-14
+    C, D = 2, sh.nshell - 1                      # an (s|d) style pair, C < D exercises the swapped order
+    nc, nd = 2 * sh.l[C] + 1, 2 * sh.l[D] + 1
+    ref = eri[:, :, sh.ao[C]:sh.ao[C] + nc, sh.ao[D]:sh.ao[D] + nd].transpose(2, 3, 0, 1).reshape(nc * nd, n, n)
+    assert np.abs(cols.cols(C, D, 0.0) - ref).max() < 1e-13
+    ranks = []
+    for tol in (1e-4, 1e-8):
+        L = cholesky_eri(sh, tol=tol)
+        ranks.append(L.shape[0])
+        assert np.abs(L - L.transpose(0, 2, 1)).max() == 0.0
+        assert np.abs(np.einsum("pij,pkl->ijkl", L, L) - eri).max() < tol
+    assert ranks[0] < ranks[1] <= n * (n + 1) // 2
