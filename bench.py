@@ -69,17 +69,7 @@ def kernel_model(name, xc, ngrid, nao):
     return 0.0, 0.0
 
 
-def host_cpu_share():
-    """CPUs this process may really use: affinity mask, cgroup quota, capped at 16 (the GPU box's
-    share for one GPU); os.cpu_count() reports the whole host (256 there)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            n = min(n, max(1, int(int(q) / int(per))))
-    except (OSError, ValueError):
-        pass
-    return max(1, min(n, 16))
+from quantum_compute_dft_amd.hostinfo import blas_threads, host_cpu_share  # noqa: E402
 
 
 def cpu_baseline(xc, dm, ao, gr, w, target_seconds):
@@ -128,6 +118,7 @@ def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=5):
     nocc = max(1, nao // 5)
     parts = {"h2d": 0.0, "jk": 0.0, "xc": 0.0, "d2h": 0.0, "host_eigh": 0.0}
     t_all = 0.0
+    pin = blas_threads(); pin.__enter__()
     for it in range(iters + 1):
         t0 = time.perf_counter()
         d_dm.copy_(torch.as_tensor(dm_h)); torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -146,6 +137,7 @@ def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=5):
             for k, a, b in (("h2d", t0, t1), ("jk", t1, t2), ("xc", t2, t3), ("d2h", t3, t4), ("host_eigh", t4, t5)):
                 parts[k] += (b - a) * 1e3 / iters
             t_all += (t5 - t0) * 1e3 / iters
+    pin.__exit__(None, None, None)
     del eri
     return {"ms": t_all, "parts_ms": parts, "eri_bytes": 8.0 * n2 * n2,
             "note": "synthetic dm/ERI; J" + ("+K one pass" if xc == "B3LYP" else "") + ", XC, host eigh (scipy) as in dft.py:199-236"}

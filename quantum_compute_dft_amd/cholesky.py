@@ -16,6 +16,12 @@ from .integrals import EriColumns
 
 def cholesky_eri(shells, tol=1e-8, span=0.01, max_vectors=None, screen=None, verbose=False):
     """Returns L of shape (naux, nao, nao), float64, every L[P] symmetric."""
+    from .hostinfo import blas_threads
+    with blas_threads():
+        return _cholesky_eri(shells, tol, span, max_vectors, screen, verbose)
+
+
+def _cholesky_eri(shells, tol, span, max_vectors, screen, verbose):
     n = shells.nao
     n2 = n * n
     eri = EriColumns(shells)

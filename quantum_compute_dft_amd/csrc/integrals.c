@@ -14,6 +14,9 @@
  * to real solid harmonics at the end.  OpenMP over shell pairs.  Plain C, no dependencies.
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
@@ -524,4 +527,15 @@ int qc_eri_cols(void *h, int C, int D, double screen, double *out)
         free(t1);
     }
     return 0;
+}
+
+/* worker threads of the OpenMP regions above (default: every visible core, which oversubscribes a
+ * cgroup CPU share) */
+void qc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }

@@ -49,7 +49,10 @@ def main(argv=None):
         if args.functional == "B3LYP":
             print(f"E_ex_hf     : {res['E_ex_hf']:.8f} Ha")
         print(f"Total Time  : {res['total_time']:.4f} s"); print("-" * 80)
-        print("Kernel Statistics (Avg per iter):"); print(f"XC(Exc+Vxc) Time: {res['xc_ms_avg']:.4f} ms"); print("-" * 80)
+        print("Kernel Statistics (Avg per iter):"); print(f"XC(Exc+Vxc) Time: {res['xc_ms_avg']:.4f} ms")
+        print(f"Median per cycle after the first: XC {res['xc_ms']:.4f} ms, J/K {res['jk_ms']:.4f} ms ({args.eri} ERI), "
+              f"whole SCF iteration {res['iter_ms']:.4f} ms ({res['cycles']} cycles)")
+        print("-" * 80)
     else:
         print("SCF Unconverged.")
 

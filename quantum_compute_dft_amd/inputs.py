@@ -56,9 +56,11 @@ def build(atom_path, basis_name="sto-3g", grid_level=3, device="cpu", verbose=Tr
         eri = integrals.int2e(shells)
     elif eri_mode == "cholesky":
         from .cholesky import cholesky_eri
+        import time
+        t0 = time.time()
         chol = cholesky_eri(shells, tol=chol_tol)
         if verbose:
-            print(f"Cholesky vectors of the ERI: {chol.shape[0]} (threshold {chol_tol:g})")
+            print(f"Cholesky vectors of the ERI: {chol.shape[0]} (threshold {chol_tol:g}, {time.time() - t0:.1f} s on the host)")
     else:
         raise ValueError(f"eri_mode {eri_mode!r}: expected 'dense' or 'cholesky'")
     return SCFInputs(symbols, xyz, shells, grids, S, T, V, T + V, eri,

@@ -43,6 +43,10 @@ def _load():
         L.qc_eri_diag.argtypes = [ctypes.c_void_p, dp]
         L.qc_eri_cols.restype = ctypes.c_int
         L.qc_eri_cols.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, dp]
+        L.qc_set_threads.restype = None
+        L.qc_set_threads.argtypes = [ctypes.c_int]
+        from .hostinfo import host_cpu_share
+        L.qc_set_threads(host_cpu_share())
         _lib = L
     return _lib
 

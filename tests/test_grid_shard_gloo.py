@@ -63,3 +63,61 @@ def test_two_rank_gloo_matches_unsharded(tmp_path, xc_type, ngrid, nao):
         assert e == pytest.approx(e_ref, rel=1e-13)
         assert np.abs(v - v_ref).max() <= 1e-12 * np.abs(v_ref).max()
     assert np.array_equal(np.load(tmp_path / "v0.npy"), np.load(tmp_path / "v1.npy"))   # replicas agree bitwise
+
+
+def test_vector_bounds_cover_the_vectors_exactly():
+    from quantum_compute_dft_amd.grid_shard import vector_bounds
+    for naux in (1, 7, 181, 3000):
+        for world in (1, 2, 3, 8):
+            blocks = [vector_bounds(naux, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == naux
+            assert all(b == c for (_, b), (c, _) in zip(blocks, blocks[1:]))
+
+
+def _fock_worker(rank, world, port, ngrid, nao, naux, nocc, out_dir):
+    from quantum_compute_dft_amd.grid_shard import ShardedFock, vector_bounds
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, ao, gr, w = synth_inputs(ngrid, nao, seed=78)
+        chol, cocc = _factors(nao, naux, nocc)
+        dm = cocc @ cocc.T
+        lo, hi = shard_bounds(ngrid, world, rank)
+        plo, phi = vector_bounds(naux, world, rank)
+
+        def local_sweep(dm_t):
+            e, v = oracle.compute_xc(2, dm_t.numpy(), ao[lo:hi], w[lo:hi], np.ascontiguousarray(gr[:, lo:hi]))
+            return e, torch.from_numpy(v)
+
+        def local_jk(dm_t, cocc_t):
+            J, K = oracle.jk_from_factors(chol[plo:phi], dm_t.numpy())
+            return torch.from_numpy(J), torch.from_numpy(K)
+
+        sf = ShardedFock(nao, local_sweep, local_jk, torch.device("cpu"))
+        res = sf.compute(torch.from_numpy(dm), torch.from_numpy(cocc))
+        np.savez(os.path.join(out_dir, f"f{rank}.npz"), v=res.vxc.numpy(), J=res.J.numpy(), K=res.K.numpy(), e=res.exc)
+    finally:
+        dist.destroy_process_group()
+
+
+def _factors(nao, naux, nocc):
+    rng = np.random.default_rng(5)
+    A = rng.normal(0, 0.3, (naux, nao, nao))
+    return 0.5 * (A + A.transpose(0, 2, 1)), rng.normal(0, 0.6, (nao, nocc))
+
+
+def test_two_rank_gloo_fock_parts_match_unsharded(tmp_path):
+    """Grid block + Cholesky-vector slice per rank, one all-reduce of [Vxc | J | K | Exc]."""
+    world, ngrid, nao, naux, nocc = 2, 211, 7, 13, 3
+    mp.spawn(_fock_worker, args=(world, _free_port(), ngrid, nao, naux, nocc, str(tmp_path)), nprocs=world, join=True)
+    _, ao, gr, w = synth_inputs(ngrid, nao, seed=78)
+    chol, cocc = _factors(nao, naux, nocc)
+    dm = cocc @ cocc.T
+    e_ref, v_ref = oracle.compute_xc(2, dm, ao, w, gr)
+    J_ref, K_ref = oracle.jk_from_factors(chol, dm)
+    r0, r1 = np.load(tmp_path / "f0.npz"), np.load(tmp_path / "f1.npz")
+    for k in ("v", "J", "K"):
+        assert np.array_equal(r0[k], r1[k])
+    assert float(r0["e"]) == pytest.approx(e_ref, rel=1e-13)
+    for got, ref in ((r0["v"], v_ref), (r0["J"], J_ref), (r0["K"], K_ref)):
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
