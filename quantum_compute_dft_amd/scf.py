@@ -39,6 +39,32 @@ class CDIIS:
         return sum(ci * Fi for ci, Fi in zip(c, self.F))
 
 
+class FockDiagonaliser:
+    """F C = S C e, the one dense eigenproblem of an SCF cycle (dft.py:181,227 `eigh(F, S)` on the host).
+    Small matrices stay on the host (LAPACK through scipy, as the reference does); from `device_from`
+    basis functions on, F is orthogonalised with X = U s^-1/2 (once per S) and diagonalised on the GPU
+    by hipSOLVER through torch.linalg.eigh -- the only library call on the device path (measured on
+    MI355X + 16 host cores: n=246 host 4.4 ms / device 6.1 ms, n=494 16.6 / 11.4 ms, n=1150 84 / 27 ms,
+    tools/eigh_time.py)."""
+
+    def __init__(self, S, device=None, device_from=400):
+        self.S, self.n = S, S.shape[0]
+        self.on_device = device is not None and self.n >= device_from
+        if self.on_device:
+            import torch
+            self.torch = torch
+            s, U = np.linalg.eigh(S)
+            self.X = torch.as_tensor(U / np.sqrt(s), dtype=torch.float64, device=device)
+
+    def __call__(self, F):
+        if not self.on_device:
+            return eigh(F, self.S)
+        t = self.torch
+        Fd = t.as_tensor(F, dtype=t.float64, device=self.X.device)
+        e, Cp = t.linalg.eigh(self.X.T @ Fd @ self.X)
+        return e.cpu().numpy(), (self.X @ Cp).cpu().numpy()
+
+
 class HipBackend:
     """Device side of the loop: libdft.so through DFTSolverWrapper, torch tensors as buffers."""
 
@@ -68,6 +94,7 @@ class HipBackend:
         self.nocc = inp.nocc
         self.d_dm = torch.zeros((nao, nao), dtype=f64, device=self.dev)
         self.d_J = torch.zeros_like(self.d_dm); self.d_K = torch.zeros_like(self.d_dm); self.d_v = torch.zeros_like(self.d_dm)
+        self.eigh = FockDiagonaliser(inp.S, self.dev)
         torch.cuda.synchronize()
         self.init_time = time.time() - t0
 
@@ -107,7 +134,8 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     functional = functional.upper()
     c_hf = 0.2 if functional == "B3LYP" else 0.0                                       # dft.py:197
     Hcore, S, nocc = inp.Hcore, inp.S, inp.nocc
-    e, C = eigh(Hcore, S)                                                              # dft.py:181
+    solve = getattr(backend, "eigh", None) or (lambda F: eigh(F, S))
+    e, C = solve(Hcore)                                                                # dft.py:181
     dm = 2.0 * C[:, :nocc] @ C[:, :nocc].T
     set_cocc = getattr(backend, "set_cocc", None)
     diis = CDIIS()
@@ -128,7 +156,7 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         Vxc = 0.5 * (Vraw + Vraw.T)                                                    # dft.py:212
         F = Hcore + J + Vxc - (c_hf * 0.5 * K if K is not None else 0.0)               # dft.py:221,223
         F = diis.update(S, dm, F)
-        e, C = eigh(F, S)
+        e, C = solve(F)
         dm_new = 2.0 * C[:, :nocc] @ C[:, :nocc].T
         E_one = float(np.sum(dm_new * Hcore)); E_coul = 0.5 * float(np.sum(dm_new * J))
         E_ex = -0.25 * c_hf * float(np.sum(dm_new * K)) if K is not None else 0.0
