@@ -33,8 +33,13 @@ constexpr int CD_BN = 256, CD_BK = 16, CD_LDB = CD_BN + 16; // 272 = 16 (mod 32)
 // workgroups of a-block 0 also accumulate sum B[g][b] * Dm[g][b] over their tile while it passes
 // through registers and leave one partial of v_P = L_P : D per (P, b-block) in vpart -- the first of
 // J's two passes over L rides along for free.
-template <int WGM, int MI, bool VECA, bool VECB, bool DOT = false>
-__global__ __launch_bounds__(BG_THREADS, 2) void k_gemm_tn(long G, int M, int N, int lda, int ldb,
+//
+// NW = waves per workgroup.  8: the tiles above, one workgroup per CU (LDS 90-106 KB).  4 (WGM = 1
+// only): tile 64 x 128, 57 KB, TWO workgroups per CU whose prologues, barriers and epilogues
+// interleave -- the half transform's contraction is only nao/16 stages long, so a lone workgroup
+// per CU spends a tenth of its life filling and draining.
+template <int WGM, int MI, bool VECA, bool VECB, bool DOT = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 2) void k_gemm_tn(long G, int M, int N, int lda, int ldb,
                                                            const double *__restrict__ A, long strideA,
                                                            const double *__restrict__ B, long strideB,
                                                            long chunk, int nB, int npair, int split,
@@ -43,10 +48,13 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_gemm_tn(long G, int M, int N,
                                                            const double *__restrict__ Dm = nullptr,
                                                            double *__restrict__ vpart = nullptr)
 {
-    constexpr int BM = 64 * WGM, WGN = 8 / WGM, NJ = CD_BN / (16 * WGN); // NJ = 4 (WGM 2) or 2 (WGM 1)
-    constexpr int LDA_ = BM + 16;                                       // 144 / 80 = 16 (mod 32)
-    constexpr int ASZ = CD_BK * LDA_, BSZ = CD_BK * CD_LDB;
-    constexpr int AH = BM / 64; // double2 loads per thread for the A tile (16 rows x 32 groups)
+    constexpr int THREADS = 64 * NW, CG = THREADS / 16;                  // 16 staging rows x CG column groups
+    constexpr int BM = 64 * WGM, WGN = NW / WGM, NJ = WGM == 2 ? 4 : 2;   // wave tile 16 MI x 16 NJ
+    constexpr int BN = 16 * NJ * WGN;                                     // 256 (NW 8) or 128 (NW 4)
+    constexpr int LDA_ = BM + 16, LDB_ = BN + 16;                         // = 16 (mod 32)
+    constexpr int ASZ = CD_BK * LDA_, BSZ = CD_BK * LDB_;
+    constexpr int AH = BM / CG / 2;                                       // double2 loads per thread, A tile
+    static_assert(BN / CG == 8, "B tile: 8 doubles per thread");
     __shared__ double lds[2 * (ASZ + BSZ)];
     double *const As = lds, *const Bs = lds + 2 * ASZ;
 
@@ -66,7 +74,7 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_gemm_tn(long G, int M, int N,
         batch = blockIdx.x / npair;
         ck = 0;
     }
-    const int a0 = (pair / nB) * BM, b0 = (pair % nB) * CD_BN;
+    const int a0 = (pair / nB) * BM, b0 = (pair % nB) * BN;
     const long glo = (long)ck * chunk, ghi = min(G, glo + chunk);
     A += batch * strideA;
     B += batch * strideB;
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_gemm_tn(long G, int M, int N,
 
     if (glo < ghi) {
         const int nst = (int)((ghi - glo + CD_BK - 1) / CD_BK);
-        const int s_row = tid >> 5, s_cq = tid & 31; // 16 rows x 32 column groups
+        const int s_row = tid / CG, s_cq = tid % CG;
         const unsigned a_voff = (unsigned)(s_row * lda + a0 + 2 * AH * s_cq) * 8u;
         const unsigned b_voff = (unsigned)(s_row * ldb + b0 + 8 * s_cq) * 8u;
         double2 ra[AH], rb[4], rd[4];
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_gemm_tn(long G, int M, int N,
             double *Ad = As + buf * ASZ + s_row * LDA_ + 2 * AH * s_cq;
 #pragma unroll
             for (int h = 0; h < AH; ++h) *reinterpret_cast<double2 *>(Ad + 2 * h) = ra[h];
-            double *Bd = Bs + buf * BSZ + s_row * CD_LDB + 8 * s_cq;
+            double *Bd = Bs + buf * BSZ + s_row * LDB_ + 8 * s_cq;
 #pragma unroll
             for (int h = 0; h < 4; ++h) *reinterpret_cast<double2 *>(Bd + 2 * h) = rb[h];
             if (DOT) {
@@ -122,14 +130,14 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_gemm_tn(long G, int M, int N,
             const int buf = st & 1;
             if (st + 1 < nst) fetch(st + 1);
             const double *Ap = As + buf * ASZ + lk * LDA_ + wm * 64 + li;
-            const double *Bp = Bs + buf * BSZ + lk * CD_LDB + wn * (16 * NJ) + li;
+            const double *Bp = Bs + buf * BSZ + lk * LDB_ + wn * (16 * NJ) + li;
 #pragma unroll
             for (int ks = 0; ks < CD_BK / 4; ++ks) {
                 double af[MI], bf[NJ];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = Ap[4 * ks * LDA_ + 16 * i];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) bf[j] = Bp[4 * ks * CD_LDB + 16 * j];
+                for (int j = 0; j < NJ; ++j) bf[j] = Bp[4 * ks * LDB_ + 16 * j];
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -138,10 +146,10 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_gemm_tn(long G, int M, int N,
             if (st + 1 < nst) stash(buf ^ 1);
             __syncthreads();
         }
-        if (DOT && dot_on) { // fixed-order workgroup sum of the 512 partial dots (the tile LDS is free now)
+        if (DOT && dot_on) { // fixed-order workgroup sum of the threads' partial dots (the tile LDS is free now)
             lds[tid] = dot;
             __syncthreads();
-            for (int w = BG_THREADS / 2; w > 0; w >>= 1) {
+            for (int w = THREADS / 2; w > 0; w >>= 1) {
                 if (tid < w) lds[tid] += lds[tid + w];
                 __syncthreads();
             }

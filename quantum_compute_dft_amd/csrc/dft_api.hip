@@ -370,11 +370,14 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
     hipStream_t st = s->stream;
     const long n2 = (long)nao * nao;
     const int nB = (nao + CD_BN - 1) / CD_BN;
+    // column blocks of the half transform: 128 wide (two 4-wave workgroups per CU) while one 64-row
+    // tile holds all occupied orbitals, 256 wide with 128-row tiles above
+    const int nBh = (K && nocc <= 64) ? (nao + 127) / 128 : nB;
     // v_P = L_P : D.  With K wanted too, the half transform reads every L_P anyway and leaves the
     // partial dots of its tiles (one per 256-column block); otherwise a pass of its own.
     const bool fused_dot = J && K;
     if (J) {
-        if (!reserve(s, s->cdv, sizeof(double) * (size_t)naux * (1 + nB), "hipMalloc(cd v)")) return -1;
+        if (!reserve(s, s->cdv, sizeof(double) * (size_t)naux * (1 + nBh), "hipMalloc(cd v)")) return -1;
         if (!fused_dot) {
             ScopedTimer t(s, "cd_dot");
             hipLaunchKernelGGL(k_cd_dot, dim3((unsigned)naux), dim3(256), 0, st, n2, L, dm, (double *)s->cdv.p);
@@ -403,21 +406,21 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
             ScopedTimer t(s, "cd_half");
             hipLaunchKernelGGL(k_pack_cocc, dim3((unsigned)(((long)nao * ldp + 255) / 256)), dim3(256), 0, st, nao, nocc, ldp, cocc, cp);
             // Yt_P (nocc x nao) = Cp^T L_P for every P
-#define QCDFT_HALF3(WGM, MI, VL, DOT)                                                                                 \
-    hipLaunchKernelGGL((k_gemm_tn<WGM, MI, true, VL, DOT>), g, dim3(BG_THREADS), 0, st, (long)nao, nocc, nao, ldp, nao, \
-                       cp, 0L, L, n2, (long)nao, nB, npair, 0, yt, ldy, (long)nocc * ldy, 0L, dm, vpart)
-#define QCDFT_HALF(WGM, MI)                                                                                           \
+#define QCDFT_HALF3(WGM, MI, VL, DOT, NW)                                                                             \
+    hipLaunchKernelGGL((k_gemm_tn<WGM, MI, true, VL, DOT, NW>), g, dim3(64 * NW), 0, st, (long)nao, nocc, nao, ldp, nao, \
+                       cp, 0L, L, n2, (long)nao, nBh, npair, 0, yt, ldy, (long)nocc * ldy, 0L, dm, vpart)
+#define QCDFT_HALF(WGM, MI, NW)                                                                                       \
     do {                                                                                                              \
-        const int nA = (nocc + 64 * WGM - 1) / (64 * WGM), npair = nA * nB;                                           \
+        const int nA = (nocc + 64 * WGM - 1) / (64 * WGM), npair = nA * nBh;                                          \
         dim3 g((unsigned)((long)npair * naux));                                                                       \
-        if (fused_dot) { if (vecL) QCDFT_HALF3(WGM, MI, true, true); else QCDFT_HALF3(WGM, MI, false, true); }        \
-        else           { if (vecL) QCDFT_HALF3(WGM, MI, true, false); else QCDFT_HALF3(WGM, MI, false, false); }      \
+        if (fused_dot) { if (vecL) QCDFT_HALF3(WGM, MI, true, true, NW); else QCDFT_HALF3(WGM, MI, false, true, NW); }   \
+        else           { if (vecL) QCDFT_HALF3(WGM, MI, true, false, NW); else QCDFT_HALF3(WGM, MI, false, false, NW); } \
     } while (0)
-            if (nocc <= 16) QCDFT_HALF(1, 1);
-            else if (nocc <= 32) QCDFT_HALF(1, 2);
-            else if (nocc <= 48) QCDFT_HALF(1, 3);
-            else if (nocc <= 64) QCDFT_HALF(1, 4);
-            else QCDFT_HALF(2, 4);
+            if (nocc <= 16) QCDFT_HALF(1, 1, 4);
+            else if (nocc <= 32) QCDFT_HALF(1, 2, 4);
+            else if (nocc <= 48) QCDFT_HALF(1, 3, 4);
+            else if (nocc <= 64) QCDFT_HALF(1, 4, 4);
+            else QCDFT_HALF(2, 4, 8);
 #undef QCDFT_HALF
 #undef QCDFT_HALF3
         }
@@ -439,7 +442,7 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
         nsl = (naux + pslice - 1) / pslice;
         if (!reserve(s, s->jpart, sizeof(double) * (size_t)nsl * n2, "hipMalloc(cd J slabs)")) return -1;
         double *jp = (double *)s->jpart.p;
-        if (fused_dot) hipLaunchKernelGGL(k_cd_vsum, dim3((unsigned)((naux + 255) / 256)), dim3(256), 0, st, naux, nB, vpart, v);
+        if (fused_dot) hipLaunchKernelGGL(k_cd_vsum, dim3((unsigned)((naux + 255) / 256)), dim3(256), 0, st, naux, nBh, vpart, v);
         hipLaunchKernelGGL(k_cd_axpy, dim3((unsigned)eb, (unsigned)nsl), dim3(256), 0, st, n2, naux, pslice, L, v, jp);
         hipLaunchKernelGGL(k_sum_slabs8, dim3((unsigned)((n2 + 31) / 32)), dim3(256), 0, st, (size_t)n2, nsl, (size_t)n2, jp, J);
     }
