@@ -107,9 +107,38 @@ _DEF2_SVP = {
     ],
 }
 
+# def2-TZVP for H and C only (Benzene: 222, Anthracene: 494 functions -- BASELINE config 3), written
+# down from memory like the tables above and NOT verifiable offline beyond the H-atom energy
+# (-0.49981 Ha, tests/test_integrals.py): treat energies in this basis as "def2-TZVP-shaped".
+_DEF2_TZVP = {
+    "H": [
+        (0, [(34.0613410, 0.60251978e-2), (5.1235746, 0.45021094e-1), (1.1646626, 0.20189726)]),
+        (0, [(0.32723041, 1.0)]),
+        (0, [(0.10307241, 1.0)]),
+        (1, [(0.8000000, 1.0)]),
+    ],
+    "C": [
+        (0, [(13575.349682, 0.22245814352e-3), (2035.2333680, 0.17232738252e-2),
+             (463.22562359, 0.89255715314e-2), (131.20019598, 0.35727984502e-1),
+             (42.853015891, 0.11076259931), (15.584185766, 0.24295627626)]),
+        (0, [(6.2067138508, 0.41440263448), (2.5764896527, 0.23744968655)]),
+        (0, [(0.57696339419, 1.0)]),
+        (0, [(0.22972831358, 1.0)]),
+        (0, [(0.95164440028e-1, 1.0)]),
+        (1, [(34.697232244, 0.53333657805e-2), (7.9582622826, 0.35864109092e-1),
+             (2.3780826883, 0.14215873329), (0.81433208183, 0.34270471845)]),
+        (1, [(0.28887547253, 1.0)]),
+        (1, [(0.10056823671, 1.0)]),
+        (2, [(1.09700000, 1.0)]),
+        (2, [(0.31800000, 1.0)]),
+        (3, [(0.76100000, 1.0)]),
+    ],
+}
+
 _BASIS_SETS = {
     "sto-3g": {s: _sto3g(s) for s in _STO3G_EXPS},
     "def2-svp": _DEF2_SVP,
+    "def2-tzvp": _DEF2_TZVP,
 }
 
 

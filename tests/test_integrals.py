@@ -110,3 +110,16 @@ def test_pivoted_cholesky_reproduces_the_dense_eri():
         assert np.abs(L - L.transpose(0, 2, 1)).max() == 0.0
         assert np.abs(np.einsum("pij,pkl->ijkl", L, L) - eri).max() < tol
     assert ranks[0] < ranks[1] <= n * (n + 1) // 2
+
+
+def test_def2_tzvp_tables_shape_and_hydrogen_atom():
+    """The def2-TZVP tables (H, C; from memory) have the published shapes -- Benzene 222, Anthracene 494
+    functions -- and the H table reproduces the published H-atom energy of that basis."""
+    from quantum_compute_dft_amd import inputs
+    for mol, nao in (("Benzene", 222), ("Anthracene", 494)):
+        syms, xyz = basis.parse_xyz(os.path.join(inputs.DATA_DIR, mol + ".xyz"))
+        assert basis.build_shells(syms, xyz, "def2-tzvp").nao == nao
+    syms, xyz = basis.parse_xyz("H 0 0 0")
+    sh = basis.build_shells(syms, xyz, "def2-tzvp")
+    S, T, V = integrals.int1e(sh, syms, xyz)
+    assert eigh(T + V, S, eigvals_only=True)[0] == pytest.approx(-0.499810, abs=2e-6)
