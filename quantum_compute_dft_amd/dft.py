@@ -21,7 +21,21 @@ def main(argv=None):
     p.add_argument("--eri", default="dense", choices=["dense", "cholesky"],
                    help="dense: the nao^4 tensor of grid.py:65; cholesky: factorised J/K (large basis sets)")
     p.add_argument("--chol-tol", type=float, default=1e-9)
+    p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 (nccl = RCCL)")
     args = p.parse_args(argv)
+
+    # one process per GPU: `python -m torch.distributed.run --nproc-per-node N -m quantum_compute_dft_amd.dft ...`
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    device = "cuda"
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        device = f"cuda:{int(os.environ.get('LOCAL_RANK', rank)) % max(1, torch.cuda.device_count())}"
+        torch.cuda.set_device(device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    if rank:  # rank 0 speaks
+        sys.stdout = open(os.devnull, "w")
 
     atom_file = args.xyzfile if args.xyzfile.lower().endswith(".xyz") else args.xyzfile + ".xyz"
     atom_path = atom_file if os.path.exists(atom_file) else os.path.join(inputs.DATA_DIR, atom_file)
@@ -30,16 +44,16 @@ def main(argv=None):
         sys.exit(1)
     print(f"=== DFT Solver: {args.functional} | Molecule: {atom_file} ===")
     print("Building CPU data...")
-    inp = inputs.build(atom_path, args.basis, args.grid_level, device="cuda", eri_mode=args.eri, chol_tol=args.chol_tol)
+    inp = inputs.build(atom_path, args.basis, args.grid_level, device=device, eri_mode=args.eri, chol_tol=args.chol_tol)
     print(f"System Info: NAO={inp.shells.nao}, Grid={inp.grids.size}, Occupied={inp.nocc}")
     print(f"Calculating AO Gradients ({args.functional} mode)..." if args.functional != "LDA" else "Skipping AO Gradients (LDA mode).")
     print("Moving data to GPU...")
     try:
-        backend = scf.HipBackend(inp, args.functional, args.lib, quirks=bool(args.quirks))
+        backend = scf.HipBackend(inp, args.functional, args.lib, quirks=bool(args.quirks), rank=rank, world=world, device=device)
     except Exception as e:  # dft.py:149-153
         print(e)
         sys.exit(1)
-    print(f"GPU Init Time: {backend.init_time:.4f}s")
+    print(f"GPU Init Time: {backend.init_time:.4f}s" + (f"  ({world} ranks: grid block + Cholesky-vector slice per GPU)" if world > 1 else ""))
     res = scf.run_scf(inp, backend, args.functional)
     if res["converged"]:
         print("-" * 80); print("Converged!")
@@ -56,7 +70,11 @@ def main(argv=None):
     else:
         print("SCF Unconverged.")
 
-    if importlib.util.find_spec("pyscf") is None:          # dft.py:272-297 needs PySCF
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if importlib.util.find_spec("pyscf") is None or rank:   # dft.py:272-297 needs PySCF
         print("\nPySCF not importable here: reference cross-check skipped.")
         return res
     print("\nRunning PySCF reference calculation...")

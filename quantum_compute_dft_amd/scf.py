@@ -66,32 +66,54 @@ class FockDiagonaliser:
 
 
 class HipBackend:
-    """Device side of the loop: libdft.so through DFTSolverWrapper, torch tensors as buffers."""
+    """Device side of the loop: libdft.so through DFTSolverWrapper, torch tensors as buffers.
 
-    def __init__(self, inp, functional, lib_path=None, quirks=True):
+    One process per GPU.  With world > 1 (torch.distributed initialised by the caller) this rank
+    keeps grid block shard_bounds(ngrid, world, rank) -- AO values are only ever evaluated for it --
+    and Cholesky-vector slice vector_bounds(naux, world, rank) resident; a cycle is the local XC
+    sweep + local J/K followed by ONE all-reduce of [Vxc | J | K | Exc] (grid_shard.ShardedFock),
+    after which every rank holds identical matrices and repeats the small host part.  A dense ERI
+    is not sharded (rank 0 contracts it): large jobs use the factorised form."""
+
+    def __init__(self, inp, functional, lib_path=None, quirks=True, rank=0, world=1, device=None, group=None):
         import torch
+        from .grid_shard import ShardedFock, shard_bounds, vector_bounds
         from .solver import DFTSolverWrapper
         assert torch.cuda.is_available(), "the SCF driver needs a GPU (there is no CPU fallback)"
-        self.torch, self.dev = torch, torch.device("cuda")
+        self.torch, self.dev = torch, torch.device(device if device is not None else "cuda")
+        if self.dev.index is not None:
+            torch.cuda.set_device(self.dev)
         self.functional = functional.upper()
         self.solver = DFTSolverWrapper(lib_path, self.functional)
         self.solver.set_option("quirks", 1 if quirks else 0)
         t0 = time.time()
-        nao, ngrid = inp.shells.nao, inp.grids.size
+        self.rank, self.world = rank, world
+        nao = inp.shells.nao
+        lo, hi = shard_bounds(inp.grids.size, world, rank)
+        ngrid = hi - lo
         self.nao, self.ngrid = nao, ngrid
         f64 = torch.float64
-        d_coords = torch.as_tensor(inp.grids.coords, dtype=f64, device=self.dev)
-        self.d_w = torch.as_tensor(inp.grids.weights, dtype=f64, device=self.dev)
-        self.d_ao = torch.empty((ngrid, nao), dtype=f64, device=self.dev)
-        self.d_gr = torch.empty((3, ngrid, nao), dtype=f64, device=self.dev) if self.functional != "LDA" else None
-        self.solver.eval_ao(inp.shells, d_coords, ngrid, self.d_ao, self.d_gr)      # grid.py:30,38 on the device
+        n1 = max(ngrid, 1)   # an empty block keeps one dummy row so every pointer stays valid; it is never swept
+        d_coords = torch.zeros((n1, 3), dtype=f64, device=self.dev)
+        self.d_w = torch.zeros(n1, dtype=f64, device=self.dev)
+        d_coords[:ngrid] = torch.as_tensor(inp.grids.coords[lo:hi], dtype=f64)
+        self.d_w[:ngrid] = torch.as_tensor(inp.grids.weights[lo:hi], dtype=f64)
+        self.d_ao = torch.zeros((n1, nao), dtype=f64, device=self.dev)
+        self.d_gr = torch.zeros((3, n1, nao), dtype=f64, device=self.dev) if self.functional != "LDA" else None
+        if ngrid:
+            self.solver.eval_ao(inp.shells, d_coords, ngrid, self.d_ao, self.d_gr)  # grid.py:30,38 on the device
         self.d_eri = self.d_chol = self.d_cocc = None
         if inp.eri is not None:
-            self.d_eri = torch.as_tensor(inp.eri.reshape(nao * nao, nao * nao), dtype=f64, device=self.dev)  # dft.py:166
+            if rank == 0:
+                self.d_eri = torch.as_tensor(inp.eri.reshape(nao * nao, nao * nao), dtype=f64, device=self.dev)  # dft.py:166
         else:  # factorised J/K (DFT_ComputeJKFactorized): Cholesky vectors stay resident instead of the ERI
-            self.d_chol = torch.as_tensor(inp.chol, dtype=f64, device=self.dev)
+            plo, phi = vector_bounds(inp.chol.shape[0], world, rank)
+            self.d_chol = torch.as_tensor(inp.chol[plo:phi], dtype=f64, device=self.dev)
             self.d_cocc = torch.zeros((nao, inp.nocc), dtype=f64, device=self.dev)
         self.nocc = inp.nocc
+        if world > 1:
+            self._sharded = ShardedFock(nao, self._local_sweep, self._local_jk, self.dev, group)
+            self.fock_parts = self._fock_parts
         self.d_dm = torch.zeros((nao, nao), dtype=f64, device=self.dev)
         self.d_J = torch.zeros_like(self.d_dm); self.d_K = torch.zeros_like(self.d_dm); self.d_v = torch.zeros_like(self.d_dm)
         self.eigh = FockDiagonaliser(inp.S, self.dev)
@@ -106,22 +128,50 @@ class HipBackend:
         if self.d_cocc is not None:
             self.d_cocc.copy_(self.torch.as_tensor(np.ascontiguousarray(cocc), dtype=self.torch.float64))
 
-    def jk(self, want_k):
-        if self.d_chol is not None:
+    def _jk_device(self, want_k):
+        """This rank's J (and K) into d_J / d_K; zeros when it holds no vectors / not the dense ERI."""
+        if self.d_chol is not None and self.d_chol.shape[0]:
             self.solver.compute_jk_factorized(self.nao, self.d_chol.shape[0], self.nocc, self.d_chol, self.d_dm,
                                               self.d_cocc if want_k else None, self.d_J, self.d_K if want_k else None)
-            return self.d_J.cpu().numpy(), (self.d_K.cpu().numpy() if want_k else None)
-        if want_k:
+        elif self.d_eri is not None and want_k:
             self.solver.compute_jk(self.nao, self.d_eri, self.d_dm, self.d_J, self.d_K)
-            return self.d_J.cpu().numpy(), self.d_K.cpu().numpy()
-        self.solver.compute_coulomb(self.nao, self.d_eri, self.d_dm, self.d_J)        # dft.py:203
-        return self.d_J.cpu().numpy(), None
+        elif self.d_eri is not None:
+            self.solver.compute_coulomb(self.nao, self.d_eri, self.d_dm, self.d_J)    # dft.py:203
+        else:
+            self.d_J.zero_(); self.d_K.zero_()
+
+    def jk(self, want_k):
+        self._jk_device(want_k)
+        return self.d_J.cpu().numpy(), (self.d_K.cpu().numpy() if want_k else None)
 
     def xc(self):
         t0 = time.time()
+        exc = self._xc_device()
+        return exc, self.d_v.cpu().numpy(), time.time() - t0
+
+    def _xc_device(self):
+        if not self.ngrid:
+            self.d_v.zero_()
+            return 0.0
         exc = self.solver.compute_xc(self.ngrid, self.nao, self.d_dm, self.d_ao, self.d_w, self.d_v, self.d_gr)
         self.torch.cuda.synchronize()                                                # dft.py:205-208
-        return exc, self.d_v.cpu().numpy(), time.time() - t0
+        return exc
+
+    # world > 1: the two local steps as ShardedFock wants them, and the all-reduced cycle
+    def _local_sweep(self, dm):
+        return self._xc_device(), self.d_v
+
+    def _local_jk(self, dm, cocc):
+        self._jk_device(self._want_k)
+        return self.d_J, (self.d_K if self._want_k else None)
+
+    def _fock_parts(self, want_k):
+        """(J, K, Exc, Vxc_raw, seconds in the local sweep) identical on every rank."""
+        self._want_k = want_k
+        t0 = time.time()
+        parts = self._sharded.compute(self.d_dm, self.d_cocc)
+        return (parts.J.cpu().numpy(), parts.K.cpu().numpy() if want_k else None, parts.exc,
+                parts.vxc.cpu().numpy(), time.time() - t0)
 
 
 def run_scf(inp, backend, functional, max_cycle=200, conv_e=1e-8, conv_dm=1e-6, log=print):
@@ -149,9 +199,13 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         backend.set_dm(dm)
         if set_cocc:
             set_cocc(np.sqrt(2.0) * C[:, :nocc])
-        J, K = backend.jk(functional == "B3LYP")
-        jk_times.append(time.time() - t_it)
-        E_xc, Vraw, t_xc = backend.xc()
+        if hasattr(backend, "fock_parts"):     # multi-GPU: local XC + local J/K, one all-reduce
+            J, K, E_xc, Vraw, t_xc = backend.fock_parts(functional == "B3LYP")
+            jk_times.append(0.0)
+        else:
+            J, K = backend.jk(functional == "B3LYP")
+            jk_times.append(time.time() - t_it)
+            E_xc, Vraw, t_xc = backend.xc()
         xc_times.append(t_xc)
         Vxc = 0.5 * (Vraw + Vraw.T)                                                    # dft.py:212
         F = Hcore + J + Vxc - (c_hf * 0.5 * K if K is not None else 0.0)               # dft.py:221,223
