@@ -6,6 +6,6 @@ package is the thin host side.  There is no CPU fallback: if the library is
 missing or no GPU is usable, calls raise.
 """
 from .build import LIB_PATH, build_library  # noqa: F401
-from .solver import DFTSolverWrapper, default_library_path  # noqa: F401
+from .solver import DFTSolverWrapper, default_library_path, load_library  # noqa: F401
 
-__all__ = ["DFTSolverWrapper", "default_library_path", "build_library", "LIB_PATH"]
+__all__ = ["DFTSolverWrapper", "default_library_path", "load_library", "build_library", "LIB_PATH"]

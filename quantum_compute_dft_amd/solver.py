@@ -23,6 +23,19 @@ def default_library_path():
     return LIB_PATH
 
 
+def load_library(lib_path=None):
+    """ctypes handle of libdft.so.  The process must end up with ONE HIP runtime: the array library
+    that owns the device buffers (torch-ROCm here, CuPy-ROCm in the reference) bundles its own
+    libamdhip64 and loads it by path, so it has to be imported BEFORE libdft.so, which then binds to
+    that copy.  Loaded the other way round, libdft.so pulls in /opt/rocm's runtime, the process holds
+    two, and whichever initialises second reports no device (measured on the MI355X box)."""
+    try:
+        import torch  # noqa: F401  (the device-buffer provider of this repo; brings the HIP runtime)
+    except ImportError:
+        pass
+    return ctypes.CDLL(os.path.abspath(lib_path or default_library_path()))
+
+
 def _ptr(a):
     """Raw device address of a torch tensor / CuPy array / int (0 for None)."""
     if a is None:
@@ -46,7 +59,7 @@ class DFTSolverWrapper:
         lib_path = lib_path or LIB_PATH
         if not os.path.exists(lib_path):
             raise FileNotFoundError(f"Shared library not found at: {lib_path}")
-        self.lib = ctypes.CDLL(os.path.abspath(lib_path))
+        self.lib = load_library(lib_path)
         self.functional_type = functional_type.upper()
         L = self.lib
         # --- the four reference symbols, declared exactly as dft.py:27-50 does

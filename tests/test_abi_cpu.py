@@ -31,7 +31,7 @@ def test_header_declares_the_four_reference_symbols():
 
 
 def test_library_exports_every_declared_symbol(libpath):
-    lib = ctypes.CDLL(libpath)
+    lib = q.load_library(libpath)
     for name in _declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/dft_solver.h but not exported"
 
@@ -54,7 +54,7 @@ def test_wrapper_error_behaviour(libpath):
 
 
 def test_bad_solver_type_returns_null_and_null_solver_is_inert(libpath):
-    lib = ctypes.CDLL(libpath)
+    lib = q.load_library(libpath)
     lib.DFT_CreateSolver.restype = ctypes.c_void_p
     lib.DFT_CreateSolver.argtypes = [ctypes.c_int]
     assert not lib.DFT_CreateSolver(7)          # dft_solver.cu:681
