@@ -15,9 +15,11 @@
 // primitive), and what matters is how the rows leave the chip.  A first version wrote
 // 32-column chunks: with four planes in flight the partial 128-byte lines it left for the
 // next chunk cost 2.6 TB/s (stores alone 200 us of 213 for Benzene/def2-SVP, compute 61 us).
-// Now a workgroup owns 16 grid points x a column block of <= 128 columns (the whole row for
-// nao <= 128): every plane's tile is staged in LDS and leaves as complete rows, 16 lanes
+// Now a workgroup owns 16 (or 8) grid points x a column block of <= 128 columns (the whole row for
+// nao <= 126): every plane's tile is staged in LDS and leaves as complete rows, 16 lanes
 // writing 256 contiguous bytes with 16-byte stores, all column groups of a row back to back.
+// Benzene/def2-SVP, four planes: 122 us = 4.3 TB/s against 82.5 us for a plain fill of the same
+// 524 MB (6.35 TB/s); the arithmetic alone is ~60 us and only partly hides behind the stores.
 // Compute mapping: lane = (point = lane & 15, shell slot = lane >> 4), 16 shells per pass over
 // the 4 waves; the host orders the shells of a block by (l, nprim) so the four shells a wave
 // evaluates together mostly share one code path.  Shell data are per-lane loads (L1/L2 hits).
@@ -27,7 +29,7 @@
 namespace qcdft {
 
 constexpr int AO_MAX_L = 3;
-constexpr int AO_PT = 16;    // grid points per workgroup
+constexpr double AO_EXP_CUT = 46.0;
 constexpr int AO_CW = 126;   // max columns per block (4 planes x 16 x 127 doubles < 64 KB)
 
 struct AoShell {
@@ -54,7 +56,9 @@ __device__ __forceinline__ void ao_put(double *tile, int plane_sz, int idx, doub
 
 // order[k], k in [shell_lo, shell_hi): shell indices of the block sorted by (l, nprim).
 // ldt: LDS leading dimension (odd, >= widest block).  Dynamic LDS: (GRAD?4:1)*AO_PT*ldt doubles.
-template <bool GRAD, bool VEC>
+// PT = grid points per workgroup (16 or 8): 8 halves the LDS tile so five workgroups fit a CU
+// (20 waves hide the exp chains and one workgroup's stores overlap the others' arithmetic).
+template <bool GRAD, bool VEC, int PT>
 __global__ __launch_bounds__(256) void k_eval_ao(long ngrid, int nao, int nchunk, int ldt,
                                                  const AoShell *__restrict__ sh,
                                                  const double *__restrict__ pexp,
@@ -66,26 +70,32 @@ __global__ __launch_bounds__(256) void k_eval_ao(long ngrid, int nao, int nchunk
                                                  double *__restrict__ grad)
 {
     extern __shared__ double tile[];
-    const int plane_sz = AO_PT * ldt;
+    constexpr int SPW = 64 / PT, NSLOT = 256 / PT, TPR = 256 / PT; // shells per wave / per pass; store threads per row
+    const int plane_sz = PT * ldt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pt = lane & 15, slot = wave * 4 + (lane >> 4); // 16 points x 16 shell slots
-    const long g0 = (long)blockIdx.x * AO_PT;
+    const int pt = lane % PT, slot = wave * SPW + lane / PT; // PT points x NSLOT shell slots
+    const long g0 = (long)blockIdx.x * PT;
     const long g = min(g0 + pt, ngrid - 1);
     const double px = coords[3 * g], py = coords[3 * g + 1], pz = coords[3 * g + 2];
-    // store mapping: row = tid >> 4, columns 32j + 2*(tid & 15) + {0,1}
-    const int srow = tid >> 4, sseg = tid & 15;
+    // store mapping: row = tid / TPR, columns 2*TPR*j + 2*(tid % TPR) + {0,1}
+    const int srow = tid / TPR, sseg = tid % TPR;
     const long grow = g0 + srow;
 
     for (int ci = 0; ci < nchunk; ++ci) {
         const AoChunk ch = chunks[ci];
-        for (int k = ch.shell_lo + slot; k < ch.shell_hi; k += 16) {
+        for (int k = ch.shell_lo + slot; k < ch.shell_hi; k += NSLOT) {
             const AoShell q = sh[order[k]];
             const double x = px - q.x, y = py - q.y, z = pz - q.z;
             const double r2 = x * x + y * y + z * z;
             double R0 = 0.0, R1 = 0.0;
             for (int p = 0; p < q.nprim; ++p) {
                 const double a = pexp[q.off + p];
-                const double e = pcoef[q.off + p] * exp(-a * r2);
+                const double t = a * r2;
+                // exp(-46) = 1e-20: a primitive that far down its tail adds nothing at fp64.  Tested per
+                // WAVE (16 consecutive grid points x 4 shells) so the branch is uniform: grid points come
+                // atom by atom and radial shell by radial shell, and most points are far from most centres.
+                if (__builtin_amdgcn_ballot_w64(t < AO_EXP_CUT) == 0) continue;
+                const double e = t < AO_EXP_CUT ? pcoef[q.off + p] * exp(-t) : 0.0;
                 R0 += e;
                 R1 -= 2.0 * a * e;
             }
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(256) void k_eval_ao(long ngrid, int nao, int nchunk
             const size_t rbase = (size_t)grow * nao + ch.col_lo;
             const size_t plane = (size_t)ngrid * nao;
             const double *t0 = tile + srow * ldt;
-            for (int c = 2 * sseg; c < ch.ncol; c += 32) {
+            for (int c = 2 * sseg; c < ch.ncol; c += 2 * TPR) {
                 if (VEC && c + 1 < ch.ncol) { // nao and col_lo even, 16-byte aligned outputs (host-checked)
                     *reinterpret_cast<double2 *>(ao + rbase + c) = make_double2(t0[c], t0[c + 1]);
                     if (GRAD) {
@@ -163,21 +173,31 @@ __global__ __launch_bounds__(256) void k_eval_ao(long ngrid, int nao, int nchunk
     }
 }
 
-inline void launch_eval_ao(hipStream_t st, long ngrid, int nao, int nchunk, int maxcol, bool vec,
+template <int PT>
+inline void launch_eval_ao_pt(hipStream_t st, long ngrid, int nao, int nchunk, int maxcol, bool vec,
+                              const AoShell *sh, const double *pexp, const double *pcoef,
+                              const AoChunk *chunks, const int *order, const double *coords, double *ao,
+                              double *grad)
+{
+    dim3 g((unsigned)((ngrid + PT - 1) / PT));
+    const int ldt = maxcol | 1;
+    const size_t lds = sizeof(double) * (grad ? 4 : 1) * PT * ldt;
+    if (grad) {
+        if (vec) hipLaunchKernelGGL((k_eval_ao<true, true, PT>), g, dim3(256), lds, st, ngrid, nao, nchunk, ldt, sh, pexp, pcoef, chunks, order, coords, ao, grad);
+        else     hipLaunchKernelGGL((k_eval_ao<true, false, PT>), g, dim3(256), lds, st, ngrid, nao, nchunk, ldt, sh, pexp, pcoef, chunks, order, coords, ao, grad);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_eval_ao<false, true, PT>), g, dim3(256), lds, st, ngrid, nao, nchunk, ldt, sh, pexp, pcoef, chunks, order, coords, ao, grad);
+        else     hipLaunchKernelGGL((k_eval_ao<false, false, PT>), g, dim3(256), lds, st, ngrid, nao, nchunk, ldt, sh, pexp, pcoef, chunks, order, coords, ao, grad);
+    }
+}
+
+inline void launch_eval_ao(hipStream_t st, long ngrid, int nao, int nchunk, int maxcol, bool vec, int pt,
                            const AoShell *sh, const double *pexp, const double *pcoef,
                            const AoChunk *chunks, const int *order, const double *coords, double *ao,
                            double *grad)
 {
-    dim3 g((unsigned)((ngrid + AO_PT - 1) / AO_PT));
-    const int ldt = maxcol | 1;
-    const size_t lds = sizeof(double) * (grad ? 4 : 1) * AO_PT * ldt;
-    if (grad) {
-        if (vec) hipLaunchKernelGGL((k_eval_ao<true, true>), g, dim3(256), lds, st, ngrid, nao, nchunk, ldt, sh, pexp, pcoef, chunks, order, coords, ao, grad);
-        else     hipLaunchKernelGGL((k_eval_ao<true, false>), g, dim3(256), lds, st, ngrid, nao, nchunk, ldt, sh, pexp, pcoef, chunks, order, coords, ao, grad);
-    } else {
-        if (vec) hipLaunchKernelGGL((k_eval_ao<false, true>), g, dim3(256), lds, st, ngrid, nao, nchunk, ldt, sh, pexp, pcoef, chunks, order, coords, ao, grad);
-        else     hipLaunchKernelGGL((k_eval_ao<false, false>), g, dim3(256), lds, st, ngrid, nao, nchunk, ldt, sh, pexp, pcoef, chunks, order, coords, ao, grad);
-    }
+    if (pt == 8) launch_eval_ao_pt<8>(st, ngrid, nao, nchunk, maxcol, vec, sh, pexp, pcoef, chunks, order, coords, ao, grad);
+    else         launch_eval_ao_pt<16>(st, ngrid, nao, nchunk, maxcol, vec, sh, pexp, pcoef, chunks, order, coords, ao, grad);
 }
 
 } // namespace qcdft

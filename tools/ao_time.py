@@ -15,11 +15,12 @@ for bname in ("sto-3g", "def2-svp"):
     ngrid = g.size
     coords = torch.as_tensor(g.coords, device=dev)
     ao = torch.empty((ngrid, sh.nao), dtype=torch.float64, device=dev); gr = torch.empty((3, ngrid, sh.nao), dtype=torch.float64, device=dev)
-    s = q.DFTSolverWrapper(sys.argv[1] if len(sys.argv) > 1 else q.build_library(), 'GGA')
-    for deriv, gg in ((0, None), (1, gr)):
+    for pt in (0, 16, 8):
+      s = q.DFTSolverWrapper(q.build_library(), 'GGA'); s.set_option('ao_pt', pt)
+      for deriv, gg in ((0, None), (1, gr)):
         for _ in range(3): s.eval_ao(sh, coords, ngrid, ao, gg)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(20): s.eval_ao(sh, coords, ngrid, ao, gg)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
         byts = ngrid * (8 * sh.nao * (4 if deriv else 1) + 24)
-        print(f"eval_ao benzene (real Becke grid {ngrid}) {bname:8s} nao={sh.nao:3d} deriv={deriv}: {dt*1e6:8.1f} us  {byts/dt/1e9:7.0f} GB/s", flush=True)
+        print(f"eval_ao benzene (real Becke grid {ngrid}) {bname:8s} nao={sh.nao:3d} deriv={deriv} points/WG={pt:2d}: {dt*1e6:8.1f} us  {byts/dt/1e9:7.0f} GB/s", flush=True)
