@@ -670,7 +670,7 @@ int DFT_EvalAO(XCSolver *s, long long ngrid, int nao, int nshell, const double *
     // 16 points per workgroup unless their LDS tile would leave fewer than three workgroups per CU
     // (measured, Benzene: def2-SVP deriv 1 139 -> 122 us with 8; STO-3G and deriv 0 are 10 % faster with 16)
     const int ao_pt = s->ao_pt ? s->ao_pt : ((d_ao_grad ? 4 : 1) * 16 * (maxcol | 1) * 8 > 53 * 1024 ? 8 : 16);
-    launch_eval_ao(s->stream, (long)ngrid, nao, nchunk, maxcol, vec, ao_pt, dsh, dexp, dcoef, dchunks, dorder,
+    launch_eval_ao(s->stream, (long)ngrid, nao, nchunk, maxcol, vec, ao_pt, s->num_cu, nshell, nprim_total, dsh, dexp, dcoef, dchunks, dorder,
                    (const double *)d_coords, (double *)d_ao, (double *)d_ao_grad);
     return hip_ok(s, hipGetLastError(), "AO launch") ? 0 : -1;
 }

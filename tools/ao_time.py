@@ -16,7 +16,7 @@ for bname in ("sto-3g", "def2-svp"):
     coords = torch.as_tensor(g.coords, device=dev)
     ao = torch.empty((ngrid, sh.nao), dtype=torch.float64, device=dev); gr = torch.empty((3, ngrid, sh.nao), dtype=torch.float64, device=dev)
     for pt in (0, 16, 8):
-      s = q.DFTSolverWrapper(q.build_library(), 'GGA'); s.set_option('ao_pt', pt)
+      s = q.DFTSolverWrapper(sys.argv[1] if len(sys.argv) > 1 else q.build_library(), 'GGA'); s.set_option('ao_pt', pt)
       for deriv, gg in ((0, None), (1, gr)):
         for _ in range(3): s.eval_ao(sh, coords, ngrid, ao, gg)
         torch.cuda.synchronize(); t0 = time.perf_counter()
