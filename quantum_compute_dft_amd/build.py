@@ -8,7 +8,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdft.so")
 SOURCES = ["dft_api.hip"]
-HEADERS = ["xc_functionals.hpp", "xc_kernels.hpp", "xc_ws_kernels.hpp", "xc_big_kernels.hpp", "jk_kernels.hpp", "ao_kernels.hpp", "cd_kernels.hpp",
+HEADERS = ["xc_functionals.hpp", "xc_kernels.hpp", "xc_ws_kernels.hpp", "xc_big_kernels.hpp", "jk_kernels.hpp", "ao_kernels.hpp", "cd_kernels.hpp", "device_util.hpp",
            os.path.join("..", "..", "include", "dft_solver.h")]
 
 

@@ -25,6 +25,7 @@
 // evaluates together mostly share one code path.  Shell data are per-lane loads (L1/L2 hits).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "device_util.hpp"
 
 namespace qcdft {
 
@@ -53,10 +54,6 @@ __device__ __forceinline__ void ao_put(double *tile, int plane_sz, int idx, doub
         tile[3 * plane_sz + idx] = R0 * Sz + t * dz;
     }
 }
-
-// LDS-only workgroup barrier.  __syncthreads() also waits for every outstanding global store
-// (s_waitcnt vmcnt(0)), which would expose the full write latency of a tile twice per tile.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // order[k], k in [shell_lo, shell_hi): shell indices of the block sorted by (l, nprim).
 // ldt: LDS leading dimension (odd, >= widest block).  Dynamic LDS: (GRAD?4:1)*PT*ldt doubles of tile,

@@ -17,6 +17,8 @@
 // 64 x 256 (wave tile 16*MI x 32) for the half transform when nocc <= 64.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include "device_util.hpp"
 #include "xc_big_kernels.hpp"
 
 namespace qcdft {
@@ -90,45 +92,48 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tn(long G, int M, int N, in
         const int s_row = tid / CG, s_cq = tid % CG;
         const unsigned a_voff = (unsigned)(s_row * lda + a0 + 2 * AH * s_cq) * 8u;
         const unsigned b_voff = (unsigned)(s_row * ldb + b0 + 8 * s_cq) * 8u;
-        double2 ra[AH], rb[4], rd[4];
+        // Two register sets: the loads of stage st+2 are issued before the MFMAs of stage st, a full
+        // stage earlier than they are needed (one stage of the half transform is only ~0.7 us of MFMA,
+        // less than an HBM round trip under load: with a one-stage prefetch its MFMA pipe was busy
+        // 57 % of the time).  Every fetch issues the same number of loads -- stages past the end go
+        // through a zero-record descriptor -- and the barriers are LDS-only, so the waits stay counted.
+        double2 ra[2][AH], rb[2][4], rd[2][4];
         double dot = 0.0;
         const bool dot_on = DOT && a0 == 0; // uniform
-        auto fetch = [&](int st) {
-            const long row0 = glo + (long)st * CD_BK; // < ghi
-            const __amdgpu_buffer_rsrc_t da = plane_tile_rsrc(A, ghi * (long)lda, row0 * lda);
-            const __amdgpu_buffer_rsrc_t db = plane_tile_rsrc(B, ghi * (long)ldb, row0 * ldb);
+        auto fetch = [&](auto S, int st) {
+            constexpr int s = decltype(S)::value;
+            const bool live = st < nst;
+            const long row0 = glo + (long)min(st, nst - 1) * CD_BK; // < ghi
+            const __amdgpu_buffer_rsrc_t da = plane_tile_rsrc(A, ghi * (long)lda, row0 * lda, live);
+            const __amdgpu_buffer_rsrc_t db = plane_tile_rsrc(B, ghi * (long)ldb, row0 * ldb, live);
 #pragma unroll
-            for (int h = 0; h < AH; ++h) ra[h] = buf_load_pair2<VECA>(da, a_voff + 16 * h, 0);
+            for (int h = 0; h < AH; ++h) ra[s][h] = buf_load_pair2<VECA>(da, a_voff + 16 * h, 0);
 #pragma unroll
-            for (int h = 0; h < 4; ++h) rb[h] = buf_load_pair2<VECB>(db, b_voff + 16 * h, 0);
+            for (int h = 0; h < 4; ++h) rb[s][h] = buf_load_pair2<VECB>(db, b_voff + 16 * h, 0);
             if (DOT) { // same rows / columns of the density matrix (ld = ldb = nao)
-                const __amdgpu_buffer_rsrc_t dd = plane_tile_rsrc(Dm, ghi * (long)ldb, row0 * ldb, dot_on);
+                const __amdgpu_buffer_rsrc_t dd = plane_tile_rsrc(Dm, ghi * (long)ldb, row0 * ldb, live && dot_on);
 #pragma unroll
-                for (int h = 0; h < 4; ++h) rd[h] = buf_load_pair2<VECB>(dd, b_voff + 16 * h, 0);
+                for (int h = 0; h < 4; ++h) rd[s][h] = buf_load_pair2<VECB>(dd, b_voff + 16 * h, 0);
             }
         };
-        auto stash = [&](int buf) {
-            double *Ad = As + buf * ASZ + s_row * LDA_ + 2 * AH * s_cq;
+        auto stash = [&](auto S) { // register set s -> LDS buffer s
+            constexpr int s = decltype(S)::value;
+            double *Ad = As + s * ASZ + s_row * LDA_ + 2 * AH * s_cq;
 #pragma unroll
-            for (int h = 0; h < AH; ++h) *reinterpret_cast<double2 *>(Ad + 2 * h) = ra[h];
-            double *Bd = Bs + buf * BSZ + s_row * LDB_ + 8 * s_cq;
+            for (int h = 0; h < AH; ++h) *reinterpret_cast<double2 *>(Ad + 2 * h) = ra[s][h];
+            double *Bd = Bs + s * BSZ + s_row * LDB_ + 8 * s_cq;
 #pragma unroll
-            for (int h = 0; h < 4; ++h) *reinterpret_cast<double2 *>(Bd + 2 * h) = rb[h];
+            for (int h = 0; h < 4; ++h) *reinterpret_cast<double2 *>(Bd + 2 * h) = rb[s][h];
             if (DOT) {
                 const int col = b0 + 8 * s_cq; // columns past N hold the next row's data: masked out
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
-                    dot += (col + 2 * h < N ? rb[h].x : 0.0) * rd[h].x;
-                    dot += (col + 2 * h + 1 < N ? rb[h].y : 0.0) * rd[h].y;
+                    dot += (col + 2 * h < N ? rb[s][h].x : 0.0) * rd[s][h].x;
+                    dot += (col + 2 * h + 1 < N ? rb[s][h].y : 0.0) * rd[s][h].y;
                 }
             }
         };
-        fetch(0);
-        stash(0);
-        __syncthreads();
-        for (int st = 0; st < nst; ++st) {
-            const int buf = st & 1;
-            if (st + 1 < nst) fetch(st + 1);
+        auto compute = [&](int buf) {
             const double *Ap = As + buf * ASZ + lk * LDA_ + wm * 64 + li;
             const double *Bp = Bs + buf * BSZ + lk * LDB_ + wn * (16 * NJ) + li;
 #pragma unroll
@@ -143,10 +148,28 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tn(long G, int M, int N, in
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
             }
-            if (st + 1 < nst) stash(buf ^ 1);
-            __syncthreads();
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        fetch(S0{}, 0);
+        fetch(S1{}, 1);
+        stash(S0{});
+        lds_barrier();
+        for (int st = 0; st < nst; st += 2) {
+            // LDS buffer 0 holds stage st, register set 1 stage st+1
+            fetch(S0{}, st + 2);
+            compute(0);
+            stash(S1{});
+            lds_barrier();
+            if (st + 1 < nst) { // uniform
+                fetch(S1{}, st + 3);
+                compute(1);
+                stash(S0{});
+                lds_barrier();
+            }
         }
         if (DOT && dot_on) { // fixed-order workgroup sum of the threads' partial dots (the tile LDS is free now)
+            __syncthreads(); // every wave is done with the tile buffers (and the loads of the dead stages have landed)
             lds[tid] = dot;
             __syncthreads();
             for (int w = THREADS / 2; w > 0; w >>= 1) {

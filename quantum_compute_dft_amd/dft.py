@@ -21,6 +21,9 @@ def main(argv=None):
     p.add_argument("--eri", default="dense", choices=["dense", "cholesky"],
                    help="dense: the nao^4 tensor of grid.py:65; cholesky: factorised J/K (large basis sets)")
     p.add_argument("--chol-tol", type=float, default=1e-9)
+    p.add_argument("--eigensolver", default="auto", choices=["auto", "exact", "subspace"],
+                   help="exact: eigh(F, S) every cycle as dft.py:227; subspace: warm-started Chebyshev-filtered subspace "
+                        "iteration with exact fallback; auto: subspace from 400 basis functions on")
     p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 (nccl = RCCL)")
     args = p.parse_args(argv)
 
@@ -49,7 +52,8 @@ def main(argv=None):
     print(f"Calculating AO Gradients ({args.functional} mode)..." if args.functional != "LDA" else "Skipping AO Gradients (LDA mode).")
     print("Moving data to GPU...")
     try:
-        backend = scf.HipBackend(inp, args.functional, args.lib, quirks=bool(args.quirks), rank=rank, world=world, device=device)
+        backend = scf.HipBackend(inp, args.functional, args.lib, quirks=bool(args.quirks), rank=rank, world=world, device=device,
+                                 eigensolver=args.eigensolver)
     except Exception as e:  # dft.py:149-153
         print(e)
         sys.exit(1)
@@ -66,6 +70,9 @@ def main(argv=None):
         print("Kernel Statistics (Avg per iter):"); print(f"XC(Exc+Vxc) Time: {res['xc_ms_avg']:.4f} ms")
         print(f"Median per cycle after the first: XC {res['xc_ms']:.4f} ms, J/K {res['jk_ms']:.4f} ms ({args.eri} ERI), "
               f"whole SCF iteration {res['iter_ms']:.4f} ms ({res['cycles']} cycles)")
+        st = getattr(backend.eigh, "stats", None)
+        if st:
+            print(f"Eigensolver: {st['subspace']} cycles by filtered subspace iteration ({st['passes']} filter passes), {st['exact']} by full diagonalisation")
         print("-" * 80)
     else:
         print("SCF Unconverged.")

@@ -35,3 +35,22 @@ def test_reference_derivative_quirks_shift_converged_energies(water):
         a = scf.run_scf(water, OracleBackend(water, fn, quirks=True), fn, log=None, conv_e=1e-11, conv_dm=1e-9)["E_tot"]
         b = scf.run_scf(water, OracleBackend(water, fn, quirks=False), fn, log=None, conv_e=1e-11, conv_dm=1e-9)["E_tot"]
         assert lo < abs(a - b) < hi, (fn, a - b)
+
+
+def test_subspace_eigensolver_reproduces_the_exact_scf():
+    """Warm-started Chebyshev-filtered subspace iteration (scf.SubspaceDiagonaliser) in place of
+    eigh(F, S): same converged energy and density as the exact loop, most cycles without a full
+    diagonalisation."""
+    inp = inputs.build("H2O", "def2-svp", 1, verbose=False)
+    kw = dict(log=None, conv_e=1e-10, conv_dm=1e-8)
+    r0 = scf.run_scf(inp, OracleBackend(inp, "B3LYP"), "B3LYP", **kw)
+    be = OracleBackend(inp, "B3LYP")
+    be.eigh = scf.SubspaceDiagonaliser(inp.S, inp.nocc)
+    r1 = scf.run_scf(inp, be, "B3LYP", **kw)
+    assert r0["converged"] and r1["converged"]
+    assert r1["E_tot"] == pytest.approx(r0["E_tot"], abs=1e-9)
+    assert np.abs(r1["dm"] - r0["dm"]).max() < 1e-7
+    assert be.eigh.stats["subspace"] > be.eigh.stats["exact"] >= 1
+    # the returned orbitals are S-orthonormal and diagonalise the last Fock matrix on their span
+    e, C = be.eigh.theta.numpy(), None
+    assert np.all(np.diff(e) >= -1e-12)
