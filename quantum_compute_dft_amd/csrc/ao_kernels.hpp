@@ -67,8 +67,9 @@ __device__ __forceinline__ void ao_put(double *tile, int plane_sz, int idx, doub
 // current tile's stores are issued, and the stores are unconditional and fixed in number (lanes
 // past the block's columns / the grid's rows repeat a neighbour's identical store) so the compiler
 // can wait for that prefetch with a counted vmcnt instead of vmcnt(0).  Ablations of the previous,
-// non-persistent form (Benzene/def2-SVP, 4 planes): stores alone 114 us against 82.5 us for a plain
-// fill, arithmetic alone 45 us, together 123 us.
+// non-persistent form, whose arithmetic read the shell table and coordinates from global memory
+// (Benzene/def2-SVP, 4 planes): stores alone 114 us against 82.5 us for a plain fill, arithmetic
+// alone 45 us, together 123 us; this form 102 us.
 template <bool GRAD, bool VEC, int PT, bool TAB>
 __global__ __launch_bounds__(256) void k_eval_ao(long ngrid, int nao, int nchunk, int ldt, int nshell,
                                                  int nprim_total,

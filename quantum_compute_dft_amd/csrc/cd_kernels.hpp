@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tn(long G, int M, int N, in
         // stage earlier than they are needed (one stage of the half transform is only ~0.7 us of MFMA,
         // less than an HBM round trip under load: with a one-stage prefetch its MFMA pipe was busy
         // 57 % of the time).  Every fetch issues the same number of loads -- stages past the end go
-        // through a zero-record descriptor -- and the barriers are LDS-only, so the waits stay counted.
+        // through a zero-record descriptor -- so the waits stay counted.
         double2 ra[2][AH], rb[2][4], rd[2][4];
         double dot = 0.0;
         const bool dot_on = DOT && a0 == 0; // uniform

@@ -4,11 +4,12 @@
 
 namespace qcdft {
 
-// LDS-only workgroup barrier.  __syncthreads() also drains every outstanding global access
-// (s_waitcnt vmcnt(0)): stores in flight and loads prefetched for later stages would all be
-// waited for at every barrier.  gfx9 counts loads and stores on the one vmcnt and retires them in
-// order, so code around this barrier has to keep its waits counted (a fixed number of younger
-// accesses), never vmcnt(0).
+// LDS-only workgroup barrier, spelled out: exactly what hipcc emits for __syncthreads() on gfx950
+// (s_waitcnt lgkmcnt(0); s_barrier -- checked in the ISA; no vmcnt wait outside tgsplit mode), written
+// as asm where a kernel's correctness argument depends on global accesses staying in flight across it.
+// The coupling to watch is elsewhere: gfx9 counts loads and stores on the one vmcnt and retires them in
+// order, so a load issued after stores cannot be waited for without waiting for those stores too, and
+// a wait the compiler cannot count (conditional accesses, unknown trip counts) becomes vmcnt(0).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 } // namespace qcdft
