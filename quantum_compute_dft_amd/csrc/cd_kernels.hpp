@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tn(long G, int M, int N, in
             }
         }
         if (DOT && dot_on) { // fixed-order workgroup sum of the threads' partial dots (the tile LDS is free now)
-            __syncthreads(); // every wave is done with the tile buffers (and the loads of the dead stages have landed)
+            __syncthreads(); // every wave is done with the tile buffers
             lds[tid] = dot;
             __syncthreads();
             for (int w = THREADS / 2; w > 0; w >>= 1) {
