@@ -14,51 +14,89 @@ from scipy.linalg import eigh
 
 
 class CDIIS:
-    """Pulay DIIS on the commutator SDF - FDS (PySCF scf.diis.CDIIS as used at dft.py:184,225)."""
+    """Pulay DIIS on the commutator SDF - FDS (PySCF scf.diis.CDIIS as used at dft.py:184,225).
+    With `device` the n^3 products and the history live on the GPU (rocBLAS through torch; only the
+    (space+1)^2 system is solved on the host): n = 494 costs 2.3 ms per cycle on 16 host cores."""
 
-    def __init__(self, space=8):
-        self.space, self.F, self.e = space, [], []
+    def __init__(self, space=8, device=None):
+        self.space, self.F, self.e, self.dev = space, [], [], device
+        if device is not None:
+            import torch
+            self.torch = torch
+            self._S = None
+
+    def _error(self, S, dm, F):
+        if self.dev is None:
+            sdf = S @ dm @ F
+            return F.copy(), (sdf.T - sdf).ravel()
+        t = self.torch
+        if self._S is None:
+            self._S = t.as_tensor(S, dtype=t.float64, device=self.dev)
+        Fd = t.as_tensor(F, dtype=t.float64, device=self.dev)
+        sdf = self._S @ t.as_tensor(dm, dtype=t.float64, device=self.dev) @ Fd
+        return Fd, (sdf.T - sdf).reshape(-1)
 
     def update(self, S, dm, F):
-        sdf = S @ dm @ F
-        self.F.append(F.copy()); self.e.append((sdf.T - sdf).ravel())
+        Fk, ek = self._error(S, dm, F)
+        self.F.append(Fk); self.e.append(ek)
         if len(self.F) > self.space:
             self.F.pop(0); self.e.pop(0)
+            if self.dev is not None:
+                self._G = self._G[1:, 1:]
         n = len(self.F)
+        if self.dev is not None:   # Gram matrix of the error vectors: only the new row (one GEMV on the GPU)
+            row = (self.torch.stack(self.e) @ ek).cpu().numpy()
+            G = np.zeros((n, n))
+            G[:n - 1, :n - 1] = getattr(self, "_G", np.zeros((0, 0)))[:n - 1, :n - 1]
+            G[n - 1, :] = G[:, n - 1] = row
+            self._G = G
         if n < 2:
             return F
         B = np.zeros((n + 1, n + 1)); B[0, 1:] = B[1:, 0] = 1.0
-        for i in range(n):
-            for j in range(i + 1):
-                B[i + 1, j + 1] = B[j + 1, i + 1] = self.e[i] @ self.e[j]
+        if self.dev is None:
+            for i in range(n):
+                for j in range(i + 1):
+                    B[i + 1, j + 1] = B[j + 1, i + 1] = self.e[i] @ self.e[j]
+        else:
+            B[1:, 1:] = self._G
         rhs = np.zeros(n + 1); rhs[0] = 1.0
         try:
             c = np.linalg.solve(B, rhs)[1:]
         except np.linalg.LinAlgError:
             c = np.linalg.lstsq(B, rhs, rcond=None)[0][1:]
-        return sum(ci * Fi for ci, Fi in zip(c, self.F))
+        if self.dev is None:
+            return sum(ci * Fi for ci, Fi in zip(c, self.F))
+        out = self.torch.zeros_like(self.F[0])
+        for ci, Fi in zip(c, self.F):
+            out.add_(Fi, alpha=float(ci))
+        return out.cpu().numpy()
 
 
 class FockDiagonaliser:
     """F C = S C e, the one dense eigenproblem of an SCF cycle (dft.py:181,227 `eigh(F, S)` on the host).
-    Small matrices stay on the host (LAPACK through scipy, as the reference does); from `device_from`
-    basis functions on, F is orthogonalised with X = U s^-1/2 (once per S) and diagonalised on the GPU
-    by hipSOLVER through torch.linalg.eigh -- the only library call on the device path (measured on
-    MI355X + 16 host cores: n=246 host 4.4 ms / device 6.1 ms, n=494 16.6 / 11.4 ms, n=1150 84 / 27 ms,
-    tools/eigh_time.py)."""
+    F is orthogonalised with X = U s^-1/2 (once per S).  Small matrices stay on the host: LAPACK dsyevd
+    on ONE thread (measured on the MI355X box, tools/eigh_threads.py: n = 114 0.67 ms on one thread
+    against 1.0 ms for scipy's generalised driver on 16; n = 246 3.2 against 4.9 ms).  From
+    `device_from` basis functions on the problem goes to the GPU: hipSOLVER through
+    torch.linalg.eigh, the only library call on the device path (n = 494: 11.4 ms against 16.5 ms on
+    16 host cores, n = 1150: 27 against 84 ms, tools/eigh_time.py)."""
 
     def __init__(self, S, device=None, device_from=400):
         self.S, self.n = S, S.shape[0]
         self.on_device = device is not None and self.n >= device_from
+        s, U = np.linalg.eigh(S)
+        self.Xh = U / np.sqrt(s)
         if self.on_device:
             import torch
             self.torch = torch
-            s, U = np.linalg.eigh(S)
-            self.X = torch.as_tensor(U / np.sqrt(s), dtype=torch.float64, device=device)
+            self.X = torch.as_tensor(self.Xh, dtype=torch.float64, device=device)
 
     def __call__(self, F):
         if not self.on_device:
-            return eigh(F, self.S)
+            from .hostinfo import blas_threads
+            with blas_threads(1):
+                e, Cp = eigh(self.Xh.T @ F @ self.Xh, driver="evd")
+                return e, self.Xh @ Cp
         t = self.torch
         Fd = t.as_tensor(F, dtype=t.float64, device=self.X.device)
         e, Cp = t.linalg.eigh(self.X.T @ Fd @ self.X)
@@ -212,6 +250,7 @@ class HipBackend:
             self.d_chol = torch.as_tensor(inp.chol[plo:phi], dtype=f64, device=self.dev)
             self.d_cocc = torch.zeros((nao, inp.nocc), dtype=f64, device=self.dev)
         self.nocc = inp.nocc
+        self.diis_device = self.dev if nao >= 200 else None   # DIIS products on the GPU once they cost more than the hops
         if world > 1:
             self._sharded = ShardedFock(nao, self._local_sweep, self._local_jk, self.dev, group)
             self.fock_parts = self._fock_parts
@@ -294,7 +333,7 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     e, C = solve(Hcore)                                                                # dft.py:181
     dm = 2.0 * C[:, :nocc] @ C[:, :nocc].T
     set_cocc = getattr(backend, "set_cocc", None)
-    diis = CDIIS()
+    diis = CDIIS(device=getattr(backend, "diis_device", None))
     if log:
         log("\nSCF started!"); log("-" * 80)
         log(f"{'epoch':>4} {'tot energy':>15} {'Δenergy':>12} {'Δdensity':>12} {'HF_Ex':>12}"); log("-" * 80)

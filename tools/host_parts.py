@@ -18,6 +18,9 @@ with blas_threads():
         d = CDIIS()
         for _ in range(8): d.update(S, dm, F + 1e-3 * rng.normal(size=(n, n)))
         t_diis = med(lambda: d.update(S, dm, F))
+        dd = CDIIS(device=torch.device("cuda"))
+        for _ in range(10): dd.update(S, dm, F + 1e-3 * rng.normal(size=(n, n)))
+        t_diis_dev = med(lambda: dd.update(S, dm, F))
         t_full = med(lambda: eigh(F, S))
         t_sub = med(lambda: eigh(F, S, subset_by_index=[0, nocc - 1]))
         fd = FockDiagonaliser(S, torch.device("cuda"), device_from=0)
@@ -27,4 +30,4 @@ with blas_threads():
         t_fock = med(lambda: F + S + 0.5 * (F + F.T) - 0.1 * S)
         Fd = torch.as_tensor(F, device="cuda")
         t_d2h = med(lambda: (Fd.cpu().numpy(), Fd.cpu().numpy(), Fd.cpu().numpy()))
-        print(f"n={n}: DIIS update {t_diis:.2f} ms | eigh host full {t_full:.2f}, host lowest-{nocc} {t_sub:.2f}, device {t_dev:.2f} ms | dm build {t_dm:.2f} | energies {t_en:.2f} | Fock sum {t_fock:.2f} | 3 D2H {t_d2h:.2f} ms", flush=True)
+        print(f"n={n}: DIIS update {t_diis:.2f} ms (device {t_diis_dev:.2f}) | eigh host full {t_full:.2f}, host lowest-{nocc} {t_sub:.2f}, device {t_dev:.2f} ms | dm build {t_dm:.2f} | energies {t_en:.2f} | Fock sum {t_fock:.2f} | 3 D2H {t_d2h:.2f} ms", flush=True)
