@@ -129,7 +129,7 @@ def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=5):
     parts = {"h2d": 0.0, "jk": 0.0, "xc": 0.0, "d2h": 0.0, "host_eigh": 0.0}
     t_all = 0.0
     want_k = xc == "B3LYP"
-    pin = blas_threads(); pin.__enter__()
+    pin = blas_threads(1 if nao < 400 else None); pin.__enter__()   # as scf.run_scf pins the host pools
     for it in range(iters + 1):
         t0 = time.perf_counter()
         d_dm.copy_(torch.as_tensor(dm_h))

@@ -93,10 +93,8 @@ class FockDiagonaliser:
 
     def __call__(self, F):
         if not self.on_device:
-            from .hostinfo import blas_threads
-            with blas_threads(1):
-                e, Cp = eigh(self.Xh.T @ F @ self.Xh, driver="evd")
-                return e, self.Xh @ Cp
+            e, Cp = eigh(self.Xh.T @ F @ self.Xh, driver="evd")   # run_scf pins the BLAS pool to one thread at this size
+            return e, self.Xh @ Cp
         t = self.torch
         Fd = t.as_tensor(F, dtype=t.float64, device=self.X.device)
         e, Cp = t.linalg.eigh(self.X.T @ Fd @ self.X)
@@ -321,7 +319,10 @@ class HipBackend:
 
 def run_scf(inp, backend, functional, max_cycle=200, conv_e=1e-8, conv_dm=1e-6, log=print):
     from .hostinfo import blas_threads
-    with blas_threads():   # host eigh / DIIS on the CPU share, not on every visible core
+    # host LAPACK/BLAS never on every visible core (256 on a 16-core share: ~90 ms stalls); below 400
+    # functions one thread is fastest for everything left on the host (dsyevd at n = 114: 0.67 ms on one
+    # thread, 0.87 on 16), above it the pool gets the CPU share
+    with blas_threads(1 if inp.S.shape[0] < 400 else None):
         return _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log)
 
 

@@ -9,16 +9,18 @@ inp = inputs.build(molname, bname, 3, device="cuda", verbose=False, eri_mode=mod
 be = scf.HipBackend(inp, fn)
 e, C = eigh(inp.Hcore, inp.S); nocc = inp.nocc
 dm = 2.0 * C[:, :nocc] @ C[:, :nocc].T
-diis = scf.CDIIS()
+diis = scf.CDIIS(device=be.diis_device)
 import torch
-for it in range(6):
+from quantum_compute_dft_amd.hostinfo import blas_threads
+pin = blas_threads(1 if inp.S.shape[0] < 400 else None); pin.__enter__()
+for it in range(8):
     t = [time.perf_counter()]
     be.set_dm(dm); be.set_cocc(np.sqrt(2.0) * C[:, :nocc]); torch.cuda.synchronize(); t.append(time.perf_counter())
     J, K = be.jk(fn == "B3LYP"); t.append(time.perf_counter())
     exc, V, _ = be.xc(); t.append(time.perf_counter())
     F = inp.Hcore + J + 0.5 * (V + V.T) - (0.1 * K if K is not None else 0.0); t.append(time.perf_counter())
     F = diis.update(inp.S, dm, F); t.append(time.perf_counter())
-    e, C = eigh(F, inp.S); t.append(time.perf_counter())
+    e, C = be.eigh(F); t.append(time.perf_counter())
     dm = 2.0 * C[:, :nocc] @ C[:, :nocc].T; t.append(time.perf_counter())
     names = ["h2d", "jk+d2h", "xc+d2h", "fock", "diis", "eigh", "dm"]
     print(it, " ".join(f"{n}={1e3*(b-a):.2f}" for n, a, b in zip(names, t[:-1], t[1:])), f"total={1e3*(t[-1]-t[0]):.2f} ms", flush=True)
