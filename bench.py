@@ -32,6 +32,8 @@ WORKLOADS = {
     "h2o_lda_def2svp": ("LDA", 24, 34310),
     "anthracene_b3lyp_def2tzvp": ("B3LYP", 494, 294868),
     "anthracene_b3lyp_sto3g": ("B3LYP", 80, 294868),
+    "anthracene_b3lyp_def2svp": ("B3LYP", 246, 294868),
+    "c33_b3lyp_def2svp": ("B3LYP", 1150, 1436406),      # BASELINE config 5 on ONE GPU: 52.9 GB of planes + 73 GB of Cholesky vectors
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_MFMA_PEAK_TF = 78.6      # AMD datasheet fp64 matrix peak (the local guide lists no fp64 figure); measured here:
@@ -126,15 +128,17 @@ def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=5):
     d_v = torch.zeros_like(d_J); d_dm = dm.clone()
     dm_h = dm.cpu().numpy()
     C = np.linalg.qr(np.random.default_rng(SEED).normal(size=(nao, nocc)))[0]
+    pin_dm = torch.empty((nao, nao), dtype=torch.float64).pin_memory()
+    pin_c = torch.empty((nao, nocc), dtype=torch.float64).pin_memory()
     parts = {"h2d": 0.0, "jk": 0.0, "xc": 0.0, "d2h": 0.0, "host_eigh": 0.0}
     t_all = 0.0
     want_k = xc == "B3LYP"
     pin = blas_threads(1 if nao < 400 else None); pin.__enter__()   # as scf.run_scf pins the host pools
     for it in range(iters + 1):
         t0 = time.perf_counter()
-        d_dm.copy_(torch.as_tensor(dm_h))
+        pin_dm.copy_(torch.as_tensor(dm_h)); d_dm.copy_(pin_dm, non_blocking=True)      # pinned staging, as scf.HipBackend
         if not dense:
-            d_c.copy_(torch.as_tensor(np.sqrt(2.0) * C[:, :nocc]))
+            pin_c.copy_(torch.as_tensor(np.ascontiguousarray(np.sqrt(2.0) * C[:, :nocc]))); d_c.copy_(pin_c, non_blocking=True)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         if not dense:
             solver.compute_jk_factorized(nao, naux, nocc, chol, d_dm, d_c if want_k else None, d_J, d_K if want_k else None)

@@ -248,6 +248,7 @@ class HipBackend:
             self.d_chol = torch.as_tensor(inp.chol[plo:phi], dtype=f64, device=self.dev)
             self.d_cocc = torch.zeros((nao, inp.nocc), dtype=f64, device=self.dev)
         self.nocc = inp.nocc
+        self._pins = {}
         self.diis_device = self.dev if nao >= 200 else None   # DIIS products on the GPU once they cost more than the hops
         if world > 1:
             self._sharded = ShardedFock(nao, self._local_sweep, self._local_jk, self.dev, group)
@@ -263,13 +264,22 @@ class HipBackend:
         torch.cuda.synchronize()
         self.init_time = time.time() - t0
 
+    def _upload(self, dst, host, key):
+        """numpy -> device through a pinned staging buffer (a pageable copy of the 10.6 MB density matrix
+        at nao 1150 took 11 ms, ~1 GB/s)."""
+        pin = self._pins.get(key)
+        if pin is None:
+            pin = self._pins[key] = self.torch.empty(dst.shape, dtype=dst.dtype).pin_memory()
+        pin.copy_(self.torch.as_tensor(np.ascontiguousarray(host), dtype=dst.dtype))
+        dst.copy_(pin, non_blocking=True)
+
     def set_dm(self, dm):
-        self.d_dm.copy_(self.torch.as_tensor(dm, dtype=self.torch.float64))       # dft.py:200
+        self._upload(self.d_dm, dm, "dm")                                         # dft.py:200
 
     def set_cocc(self, cocc):
         """cocc (nao, nocc) with dm = cocc cocc^T; only the factorised exchange needs it."""
         if self.d_cocc is not None:
-            self.d_cocc.copy_(self.torch.as_tensor(np.ascontiguousarray(cocc), dtype=self.torch.float64))
+            self._upload(self.d_cocc, cocc, "cocc")
 
     def _jk_device(self, want_k):
         """This rank's J (and K) into d_J / d_K; zeros when it holds no vectors / not the dense ERI."""
