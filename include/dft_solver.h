@@ -140,7 +140,8 @@ int DFT_EvalAO(XCSolver *solver, long long ngrid, int nao, int nshell,
  * of the generic Vxc contraction; 0 = auto), "spin_wait" (1, default: the host
  * polls the host-mapped Exc word written by the last kernel instead of sleeping
  * in hipStreamSynchronize), "ao_pt" (grid points per workgroup of DFT_EvalAO:
- * 8, 16, or 0 = auto).  Returns 0 if the key is known. */
+ * 8, 16, or 0 = auto), "rho_rows" (grid rows per workgroup of the large-basis
+ * density kernel: 64, default, or 128).  Returns 0 if the key is known. */
 int DFT_SetOption(XCSolver *solver, const char *key, double value);
 
 /* Run subsequent work on `hip_stream` (a hipStream_t cast to an integer);

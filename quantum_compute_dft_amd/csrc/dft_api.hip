@@ -52,6 +52,7 @@ struct XCSolver {
     int profile = 0;
     int ksplit = 0;
     int ao_pt = 0; // grid points per workgroup of the AO kernel: 0 auto, 8 or 16
+    int rho_rows = 64; // grid rows per workgroup of the large-basis rho kernel: 64 (two workgroups per CU) or 128
     // workspace
     DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells, msym, cdy, cdc, cdv;
     int spin_wait = 1; // poll the host-mapped Exc instead of sleeping in hipStreamSynchronize
@@ -236,11 +237,19 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
             else     { if (vec16) { QCDFT_RHO(false, true) } else { QCDFT_RHO(false, false) } }
 #undef QCDFT_RHO
         } else if (big) {
-            dim3 g((unsigned)((ngrid + BG_BM - 1) / BG_BM));
-            if (gga) { if (vec16) hipLaunchKernelGGL((k_rho_big<true, true>), g, dim3(BG_THREADS), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
-                       else       hipLaunchKernelGGL((k_rho_big<true, false>), g, dim3(BG_THREADS), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma); }
-            else     { if (vec16) hipLaunchKernelGGL((k_rho_big<false, true>), g, dim3(BG_THREADS), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
-                       else       hipLaunchKernelGGL((k_rho_big<false, false>), g, dim3(BG_THREADS), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma); }
+            if (s->rho_rows == 128) {
+                dim3 g((unsigned)((ngrid + BG_BM - 1) / BG_BM));
+                if (gga) { if (vec16) hipLaunchKernelGGL((k_rho_big<true, true>), g, dim3(BG_THREADS), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
+                           else       hipLaunchKernelGGL((k_rho_big<true, false>), g, dim3(BG_THREADS), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma); }
+                else     { if (vec16) hipLaunchKernelGGL((k_rho_big<false, true>), g, dim3(BG_THREADS), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
+                           else       hipLaunchKernelGGL((k_rho_big<false, false>), g, dim3(BG_THREADS), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma); }
+            } else { // 64-row workgroups, two per CU
+                dim3 g((unsigned)((ngrid + R6_BM - 1) / R6_BM));
+                if (gga) { if (vec16) hipLaunchKernelGGL((k_rho_big64<true, true>), g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
+                           else       hipLaunchKernelGGL((k_rho_big64<true, false>), g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma); }
+                else     { if (vec16) hipLaunchKernelGGL((k_rho_big64<false, true>), g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
+                           else       hipLaunchKernelGGL((k_rho_big64<false, false>), g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma); }
+            }
         } else if (s->path != 1) {
             dim3 g((unsigned)((ngrid + 63) / 64));
             if (gga) hipLaunchKernelGGL(k_rho_mfma<true>, g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
@@ -682,6 +691,7 @@ int DFT_SetOption(XCSolver *s, const char *key, double value)
     if (!strcmp(key, "path")) { s->path = (int)value; return 0; }
     if (!strcmp(key, "profile")) { s->profile = value != 0.0; return 0; }
     if (!strcmp(key, "spin_wait")) { s->spin_wait = value != 0.0; return 0; }
+    if (!strcmp(key, "rho_rows")) { s->rho_rows = value == 128.0 ? 128 : 64; return 0; }
     if (!strcmp(key, "ao_pt")) { s->ao_pt = value == 16.0 ? 16 : value == 8.0 ? 8 : 0; return 0; }
     if (!strcmp(key, "ksplit")) { s->ksplit = value > 0 ? (int)value : 0; return 0; }
     return -1;

@@ -18,6 +18,7 @@
 // References replaced: src/dft_solver.cu:294-307,346-380 (rho), :309-513 pass 2 + :541-548 (Vxc).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "xc_ws_kernels.hpp"
 
 namespace qcdft {
@@ -138,53 +139,69 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_rho_big(long ngrid, int nao, 
             __syncthreads();
         }
 
-        // row dots of this 128 x 128 block of X, four 32-row slabs through LDS
-        double *Xs = lds; // 32 x RB_LDB doubles = 36,864 B
+        // Row dots of this 128 x 128 block of X.  The whole X tile goes to LDS at once (the staging
+        // buffers are dead here), then four passes of 32 rows in the coalesced (row, seg) mapping with
+        // the plane loads of pass p+1 in flight under the arithmetic of pass p -- the accumulators'
+        // registers are free by then.  (Slab by slab with two barriers and an exposed L2 round trip
+        // each, this epilogue was 31 % of the kernel at nao 246 and 16 % at 494.)
+        {
+            constexpr int XLD = RB_BN + 8; // 136: 128 x 136 doubles = 139,264 B <= the staging LDS
+            double *Xs = lds;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            if (wm == (p >> 1)) {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int r = 0; r < 4; ++r)
+                        Xs[(wm * 64 + 16 * i + lk + 4 * r) * XLD + wn * 32 + 16 * j + li] = acc[i][j][r];
+            double2 v[2][4][4]; // [set][plane][column group]
+            const unsigned voff = (unsigned)(e_row * nao + n0 + 2 * e_seg) * 8u;
+            auto issue = [&](auto S, int p) {
+                constexpr int st = decltype(S)::value;
+                const long row0 = g0 + 32 * p;                     // wave-uniform
+                const bool live = row0 < ngrid;
+                const long e0 = (live ? row0 : 0) * (long)nao;
+                const __amdgpu_buffer_rsrc_t r0 = plane_tile_rsrc(ao, plane, e0, live);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            Xs[(16 * ii + lk + 4 * r) * RB_LDB + wn * 32 + 16 * j + li] = acc[2 * (p & 1) + ii][j][r];
-            }
-            __syncthreads();
-            {
-                const long row0 = g0 + 32 * p;                 // slab's first grid row (wave-uniform)
-                const bool slab_ok = row0 < ngrid;              // uniform
-                const long e0 = (slab_ok ? row0 : 0) * (long)nao;
-                const unsigned voff = (unsigned)(e_row * nao + n0 + 2 * e_seg) * 8u;
-                const __amdgpu_buffer_rsrc_t r0 = plane_tile_rsrc(ao, plane, e0);
-                double2 v0[4], v1[4], v2[4], v3[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v0[q] = buf_load_pair2<VEC>(r0, voff, (unsigned)(32 * q) * 8u);
+                for (int q = 0; q < 4; ++q) v[st][0][q] = buf_load_pair2<VEC>(r0, voff, (unsigned)(32 * q) * 8u);
                 if (GRAD) {
-                    const __amdgpu_buffer_rsrc_t r1 = plane_tile_rsrc(gx, plane, e0);
-                    const __amdgpu_buffer_rsrc_t r2 = plane_tile_rsrc(gy, plane, e0);
-                    const __amdgpu_buffer_rsrc_t r3 = plane_tile_rsrc(gz, plane, e0);
+                    const __amdgpu_buffer_rsrc_t r1 = plane_tile_rsrc(gx, plane, e0, live);
+                    const __amdgpu_buffer_rsrc_t r2 = plane_tile_rsrc(gy, plane, e0, live);
+                    const __amdgpu_buffer_rsrc_t r3 = plane_tile_rsrc(gz, plane, e0, live);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        v1[q] = buf_load_pair2<VEC>(r1, voff, (unsigned)(32 * q) * 8u);
-                        v2[q] = buf_load_pair2<VEC>(r2, voff, (unsigned)(32 * q) * 8u);
-                        v3[q] = buf_load_pair2<VEC>(r3, voff, (unsigned)(32 * q) * 8u);
+                        v[st][1][q] = buf_load_pair2<VEC>(r1, voff, (unsigned)(32 * q) * 8u);
+                        v[st][2][q] = buf_load_pair2<VEC>(r2, voff, (unsigned)(32 * q) * 8u);
+                        v[st][3][q] = buf_load_pair2<VEC>(r3, voff, (unsigned)(32 * q) * 8u);
                     }
                 }
+            };
+            auto dots = [&](auto S, int p) {
+                constexpr int st = decltype(S)::value;
                 double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const double2 x = *reinterpret_cast<const double2 *>(&Xs[e_row * RB_LDB + 32 * q + 2 * e_seg]);
-                    t0 += x.x * v0[q].x + x.y * v0[q].y;
+                    const double2 x = *reinterpret_cast<const double2 *>(&Xs[(32 * p + e_row) * XLD + 32 * q + 2 * e_seg]);
+                    t0 += x.x * v[st][0][q].x + x.y * v[st][0][q].y;
                     if (GRAD) {
-                        t1 += x.x * v1[q].x + x.y * v1[q].y;
-                        t2 += x.x * v2[q].x + x.y * v2[q].y;
-                        t3 += x.x * v3[q].x + x.y * v3[q].y;
+                        t1 += x.x * v[st][1][q].x + x.y * v[st][1][q].y;
+                        t2 += x.x * v[st][2][q].x + x.y * v[st][2][q].y;
+                        t3 += x.x * v[st][3][q].x + x.y * v[st][3][q].y;
                     }
                 }
-                if (slab_ok) { s0[p] += t0; s1[p] += t1; s2[p] += t2; s3[p] += t3; }
-            }
+                s0[p] += t0; s1[p] += t1; s2[p] += t2; s3[p] += t3; // rows past the grid loaded zeros
+            };
+            using E0 = std::integral_constant<int, 0>;
+            using E1 = std::integral_constant<int, 1>;
+            issue(E0{}, 0);
+            __syncthreads();
+            issue(E1{}, 1);
+            dots(E0{}, 0);
+            issue(E0{}, 2);
+            dots(E1{}, 1);
+            issue(E1{}, 3);
+            dots(E0{}, 2);
+            dots(E1{}, 3);
             __syncthreads();
         }
     }
@@ -199,6 +216,184 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_rho_big(long ngrid, int nao, 
             t3 = row16_sum(s3[p]);
         }
         const long g = g0 + 32 * p + e_row;
+        if (e_seg == 0 && g < ngrid) {
+            rho[g] = t0;
+            if (GRAD) {
+                const double ax = 2.0 * t1, ay = 2.0 * t2, az = 2.0 * t3;
+                grad[3 * g + 0] = ax;
+                grad[3 * g + 1] = ay;
+                grad[3 * g + 2] = az;
+                sigma[g] = ax * ax + ay * ay + az * az;
+            }
+        }
+    }
+}
+
+// 64-row variant: 256 threads = 4 waves (2 x 2, wave tile 32 x 64), BK = 16, 69.6 KB of LDS, so TWO
+// workgroups share a CU and one's epilogue -- which is bound by the per-CU fill rate: 524 KB of plane
+// tiles per 128-column block, ~22 us at the ~10 B/cycle a CU gets from HBM, against ~54 us of MFMA --
+// runs under the other's MFMA loop.  (With one 128-row workgroup per CU that traffic was exposed:
+// 31 % of the kernel at nao 246, 16 % at 494; fewer barriers and deeper prefetch inside the epilogue
+// changed nothing.)
+constexpr int R6_BM = 64, R6_BK = 16, R6_LDA = R6_BK + 2, R6_XLD = RB_BN + 8; // A ld 18, X ld 136
+template <bool GRAD, bool VEC>
+__global__ __launch_bounds__(256, 2) void k_rho_big64(long ngrid, int nao, int NP,
+                                                      const double *__restrict__ ao,
+                                                      const double *__restrict__ gx,
+                                                      const double *__restrict__ gy,
+                                                      const double *__restrict__ gz,
+                                                      const double *__restrict__ Dp,
+                                                      double *__restrict__ rho,
+                                                      double *__restrict__ grad,
+                                                      double *__restrict__ sigma)
+{
+    constexpr int ASZ = R6_BM * R6_LDA, BSZ = R6_BK * RB_LDB;    // doubles per stage
+    constexpr int STAGE = 2 * (ASZ + BSZ), XSZ = R6_BM * R6_XLD; // 6912 / 8704 doubles
+    __shared__ double lds[XSZ > STAGE ? XSZ : STAGE];            // 69,632 B; the X tile aliases the staging
+    double *const As = lds, *const Bs = lds + 2 * ASZ;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1; // rows wm*32 + 16i (i<2), columns wn*64 + 16j (j<4)
+    const long g0 = (long)blockIdx.x * R6_BM;
+    const long plane = ngrid * (long)nao;
+    const int nkc = (NP + R6_BK - 1) / R6_BK;
+
+    const int a_row = tid >> 2, a_kq = tid & 3;   // A: 64 rows x 4 quads of k
+    const int b_row = tid >> 4, b_cq = tid & 15;  // B: 16 k-rows x 16 octets of n
+    const unsigned a_voff = (unsigned)(a_row * nao + 4 * a_kq) * 8u;
+    const __amdgpu_buffer_rsrc_t ra = plane_tile_rsrc(ao, plane, g0 * nao);
+    const int e_row = tid >> 4, e_seg = tid & 15; // epilogue: 16 rows x 16 segs per pass
+
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, s3[4] = {0, 0, 0, 0};
+
+    for (int n0 = 0; n0 < NP; n0 += RB_BN) {
+        d4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+        double2 rav[2], rb[4];
+        auto fetch = [&](int kc) {
+            const unsigned soff = (unsigned)(kc * R6_BK) * 8u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) rav[q] = buf_load_pair2<VEC>(ra, a_voff + 16 * q, soff);
+            const int k = kc * R6_BK + b_row, n = n0 + 8 * b_cq;
+            const bool ok = k < NP && n < NP; // NP is a multiple of 16: an octet is inside or outside
+            const double2 *src = reinterpret_cast<const double2 *>(Dp + (size_t)(ok ? k : 0) * NP + (ok ? n : 0));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double2 v = src[q];
+                rb[q] = ok ? v : make_double2(0.0, 0.0);
+            }
+        };
+        auto stash = [&](int buf) {
+            double *A = As + buf * ASZ + a_row * R6_LDA + 4 * a_kq;
+            double *B = Bs + buf * BSZ + b_row * RB_LDB + 8 * b_cq;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) *reinterpret_cast<double2 *>(A + 2 * q) = rav[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<double2 *>(B + 2 * q) = rb[q];
+        };
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (int kc = 0; kc < nkc; ++kc) {
+            const int buf = kc & 1;
+            if (kc + 1 < nkc) fetch(kc + 1);
+            const double *A = As + buf * ASZ + (wm * 32 + li) * R6_LDA + lk;
+            const double *B = Bs + buf * BSZ + lk * RB_LDB + wn * 64 + li;
+#pragma unroll
+            for (int ks = 0; ks < R6_BK / 4; ++ks) {
+                double af[2], bf[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = A[16 * i * R6_LDA + 4 * ks];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = B[4 * ks * RB_LDB + 16 * j];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
+            }
+            if (kc + 1 < nkc) stash(buf ^ 1);
+            __syncthreads();
+        }
+
+        // row dots of this 64 x 128 block of X: whole tile to LDS, four passes of 16 rows, the plane loads
+        // of pass p+1 in flight under the arithmetic of pass p
+        {
+            double *Xs = lds;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Xs[(wm * 32 + 16 * i + lk + 4 * r) * R6_XLD + wn * 64 + 16 * j + li] = acc[i][j][r];
+            double2 v[2][4][4]; // [set][plane][column group]
+            const unsigned voff = (unsigned)(e_row * nao + n0 + 2 * e_seg) * 8u;
+            auto issue = [&](auto S, int p) {
+                constexpr int st = decltype(S)::value;
+                const long row0 = g0 + 16 * p;                     // wave-uniform
+                const bool live = row0 < ngrid;
+                const long e0 = (live ? row0 : 0) * (long)nao;
+                const __amdgpu_buffer_rsrc_t r0 = plane_tile_rsrc(ao, plane, e0, live);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[st][0][q] = buf_load_pair2<VEC>(r0, voff, (unsigned)(32 * q) * 8u);
+                if (GRAD) {
+                    const __amdgpu_buffer_rsrc_t r1 = plane_tile_rsrc(gx, plane, e0, live);
+                    const __amdgpu_buffer_rsrc_t r2 = plane_tile_rsrc(gy, plane, e0, live);
+                    const __amdgpu_buffer_rsrc_t r3 = plane_tile_rsrc(gz, plane, e0, live);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[st][1][q] = buf_load_pair2<VEC>(r1, voff, (unsigned)(32 * q) * 8u);
+                        v[st][2][q] = buf_load_pair2<VEC>(r2, voff, (unsigned)(32 * q) * 8u);
+                        v[st][3][q] = buf_load_pair2<VEC>(r3, voff, (unsigned)(32 * q) * 8u);
+                    }
+                }
+            };
+            auto dots = [&](auto S, int p) {
+                constexpr int st = decltype(S)::value;
+                double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double2 x = *reinterpret_cast<const double2 *>(&Xs[(16 * p + e_row) * R6_XLD + 32 * q + 2 * e_seg]);
+                    t0 += x.x * v[st][0][q].x + x.y * v[st][0][q].y;
+                    if (GRAD) {
+                        t1 += x.x * v[st][1][q].x + x.y * v[st][1][q].y;
+                        t2 += x.x * v[st][2][q].x + x.y * v[st][2][q].y;
+                        t3 += x.x * v[st][3][q].x + x.y * v[st][3][q].y;
+                    }
+                }
+                s0[p] += t0; s1[p] += t1; s2[p] += t2; s3[p] += t3; // rows past the grid loaded zeros
+            };
+            using E0 = std::integral_constant<int, 0>;
+            using E1 = std::integral_constant<int, 1>;
+            issue(E0{}, 0);
+            __syncthreads();
+            issue(E1{}, 1);
+            dots(E0{}, 0);
+            issue(E0{}, 2);
+            dots(E1{}, 1);
+            issue(E1{}, 3);
+            dots(E0{}, 2);
+            dots(E1{}, 3);
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const double t0 = row16_sum(s0[p]);
+        double t1 = 0, t2 = 0, t3 = 0;
+        if (GRAD) {
+            t1 = row16_sum(s1[p]);
+            t2 = row16_sum(s2[p]);
+            t3 = row16_sum(s3[p]);
+        }
+        const long g = g0 + 16 * p + e_row;
         if (e_seg == 0 && g < ngrid) {
             rho[g] = t0;
             if (GRAD) {
