@@ -104,7 +104,7 @@ def cpu_baseline(xc, dm, ao, gr, w, target_seconds):
                       f"{threads} threads"}
 
 
-def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=5):
+def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=9):
     """One SCF iteration as dft.py:199-236 does it, on the same synthetic shapes: H2D dm, J (+K for
     B3LYP), XC sweep, D2H, host Fock build + the dense eigenproblem.  nao <= 200: J/K from one pass
     over a synthetic dense ERI (the reference's formulation); above, where 8 nao^4 bytes stop being
@@ -130,8 +130,7 @@ def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=5):
     C = np.linalg.qr(np.random.default_rng(SEED).normal(size=(nao, nocc)))[0]
     pin_dm = torch.empty((nao, nao), dtype=torch.float64).pin_memory()
     pin_c = torch.empty((nao, nocc), dtype=torch.float64).pin_memory()
-    parts = {"h2d": 0.0, "jk": 0.0, "xc": 0.0, "d2h": 0.0, "host_eigh": 0.0}
-    t_all = 0.0
+    rows = []
     want_k = xc == "B3LYP"
     pin = blas_threads(1 if nao < 400 else None); pin.__enter__()   # as scf.run_scf pins the host pools
     for it in range(iters + 1):
@@ -153,10 +152,15 @@ def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=5):
         F = H + 1e-3 * (J + 0.5 * (V + V.T) - 0.1 * K)
         e, C = solve(F); dm_new = 2.0 * C[:, :nocc] @ C[:, :nocc].T
         t5 = time.perf_counter()
+        if os.environ.get("QCDFT_BENCH_DEBUG"):
+            print(f"[scf_iteration {it}] h2d {1e3*(t1-t0):.2f} jk {1e3*(t2-t1):.2f} xc {1e3*(t3-t2):.2f} d2h {1e3*(t4-t3):.2f} host {1e3*(t5-t4):.2f} ms", file=sys.stderr, flush=True)
         if it:  # first iteration warms allocations
-            for k, a, b in (("h2d", t0, t1), ("jk", t1, t2), ("xc", t2, t3), ("d2h", t3, t4), ("host_eigh", t4, t5)):
-                parts[k] += (b - a) * 1e3 / iters
-            t_all += (t5 - t0) * 1e3 / iters
+            rows.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5 - t0))
+    # medians: a 16-core share of a 256-core host stalls a cycle for tens of ms now and then (seen: one
+    # 24 ms host part among 15 cycles of 0.7 ms); the worst cycle is reported next to them
+    med = 1e3 * np.median(np.array(rows), axis=0)
+    parts = dict(zip(("h2d", "jk", "xc", "d2h", "host_eigh"), (float(v) for v in med[:5])))
+    t_all, t_worst = float(med[5]), 1e3 * max(r[5] for r in rows)
     pin.__exit__(None, None, None)
     if dense:
         del eri
@@ -164,7 +168,7 @@ def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=5):
         del chol
     torch.cuda.empty_cache()
     how = ("one pass over a synthetic dense ERI" if dense else f"{naux} synthetic Cholesky vectors (factorised)")
-    return {"ms": t_all, "parts_ms": parts, "eri_bytes": store,
+    return {"ms": t_all, "parts_ms": parts, "statistic": f"median of {iters} cycles", "worst_cycle_ms": t_worst, "eri_bytes": store,
             "eigh": "hipSOLVER on the device" if solve.on_device else "host LAPACK (scipy)",
             "note": "synthetic dm; J" + ("+K" if want_k else "") + f" from {how}, XC, Fock build + eigh as in dft.py:199-236"}
 
@@ -224,6 +228,13 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo only to rehearse N>1 on a single card")
     args = ap.parse_args()
+
+    # Host BLAS/OpenMP pools on the CPU share from the first numpy call on: left at one thread per
+    # visible core (256), the workers of a single BLAS call spin long enough after it to exhaust the
+    # cgroup's CPU quota, and the whole process is throttled for tens of ms somewhere later (seen as
+    # one 24-90 ms cycle among 0.7 ms ones).
+    _pool_pin = blas_threads()
+    _pool_pin.__enter__()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

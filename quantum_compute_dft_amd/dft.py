@@ -45,6 +45,9 @@ def main(argv=None):
     if not os.path.exists(atom_path):
         print(f"Error: {atom_path} not found.")
         sys.exit(1)
+    from .hostinfo import blas_threads
+    _pool_pin = blas_threads()   # host BLAS/OpenMP pools on the CPU share from the first numpy call on (hostinfo.py)
+    _pool_pin.__enter__()
     print(f"=== DFT Solver: {args.functional} | Molecule: {atom_file} ===")
     print("Building CPU data...")
     inp = inputs.build(atom_path, args.basis, args.grid_level, device=device, eri_mode=args.eri, chol_tol=args.chol_tol)

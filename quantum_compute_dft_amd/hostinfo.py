@@ -17,9 +17,11 @@ def host_cpu_share(cap=16):
 
 
 def blas_threads(n=None):
-    """Context manager pinning the BLAS/LAPACK pools behind numpy/scipy to the CPU share: with one
-    thread per visible core (256) the nao x nao eigh of an SCF cycle stalls for ~90 ms every few
-    calls on a 16-core share (measured, Benzene/def2-SVP: 0.95 ms pinned)."""
+    """Context manager pinning the BLAS/LAPACK/OpenMP pools behind numpy/scipy to the CPU share.  With
+    one thread per visible core (256 on the GPU box) the workers of one BLAS call keep spinning after
+    it; on a 16-core cgroup share that exhausts the CPU quota and the whole process is throttled for
+    tens of ms a little later -- seen as an SCF cycle whose 0.7 ms `eigh` takes 25-90 ms every few
+    calls.  Entry points (bench.py, dft.py) enter this before their first numpy call."""
     try:
         from threadpoolctl import threadpool_limits
     except ImportError:
