@@ -269,6 +269,7 @@ typedef struct {
     const int *ls, *nprim, *off, *ao0;
     int *pA, *pB;
     PrimPair **pairs;
+    int *npp;     /* significant primitive pairs kept per shell pair */
     double *qmax; /* Schwarz bound sqrt(max (ab|ab)) per shell pair, filled by qc_eri_diag */
     /* owned copies of the shell table (the context outlives the caller's arrays) */
     double *own_xyz, *own_ex, *own_cf;
@@ -282,6 +283,7 @@ static void ctx_build_pairs(EriCtx *c)
     const int nshell = c->nshell;
     c->npairs = nshell * (nshell + 1) / 2;
     c->pairs = (PrimPair **)calloc(c->npairs, sizeof(PrimPair *));
+    c->npp = (int *)calloc(c->npairs, sizeof(int));
     c->pA = (int *)malloc(sizeof(int) * c->npairs);
     c->pB = (int *)malloc(sizeof(int) * c->npairs);
     c->qmax = NULL;
@@ -291,18 +293,27 @@ static void ctx_build_pairs(EriCtx *c)
     for (int k = 0; k < c->npairs; ++k) {
         const int A = c->pA[k], B = c->pB[k];
         c->pairs[k] = (PrimPair *)malloc(sizeof(PrimPair) * c->nprim[A] * c->nprim[B]);
+        /* primitive pairs whose Gaussian-product prefactor |c_a c_b| exp(-mu R_AB^2) is below 1e-18 are
+         * dropped here once: tight primitives on different centres make up most of a contracted pair's
+         * nprim[A]*nprim[B] products and contribute nothing at fp64 */
+        const double *RA = c->xyz + 3 * A, *RB = c->xyz + 3 * B;
+        const double R2 = (RA[0] - RB[0]) * (RA[0] - RB[0]) + (RA[1] - RB[1]) * (RA[1] - RB[1]) + (RA[2] - RB[2]) * (RA[2] - RB[2]);
+        int kept = 0;
         for (int a = 0; a < c->nprim[A]; ++a)
-            for (int b = 0; b < c->nprim[B]; ++b)
-                make_pair(c->ls[A], c->ls[B], c->ex[c->off[A] + a], c->ex[c->off[B] + b], c->xyz + 3 * A,
-                          c->xyz + 3 * B, c->cf[c->off[A] + a] * c->cf[c->off[B] + b],
-                          &c->pairs[k][a * c->nprim[B] + b]);
+            for (int b = 0; b < c->nprim[B]; ++b) {
+                const double ea = c->ex[c->off[A] + a], eb = c->ex[c->off[B] + b];
+                const double cc = c->cf[c->off[A] + a] * c->cf[c->off[B] + b];
+                if (fabs(cc) * exp(-ea * eb / (ea + eb) * R2) < 1e-18) continue;
+                make_pair(c->ls[A], c->ls[B], ea, eb, RA, RB, cc, &c->pairs[k][kept++]);
+            }
+        c->npp[k] = kept;
     }
 }
 
 static void ctx_free_pairs(EriCtx *c)
 {
     for (int k = 0; k < c->npairs; ++k) free(c->pairs[k]);
-    free(c->pairs); free(c->pA); free(c->pB); free(c->qmax);
+    free(c->pairs); free(c->pA); free(c->pB); free(c->qmax); free(c->npp);
 }
 
 #define QUARTET_DOUBLES (MAXCART * MAXCART * MAXCART * MAXCART)
@@ -312,7 +323,7 @@ static void ctx_free_pairs(EriCtx *c)
 static void quartet(const EriCtx *c, int kab, int kcd, double *cart, double *t1, double R[RDIM][RDIM][RDIM])
 {
     const int A = c->pA[kab], B = c->pB[kab], C = c->pA[kcd], D = c->pB[kcd];
-    const int *ls = c->ls, *nprim = c->nprim;
+    const int *ls = c->ls;
     const int la = ls[A], lb = ls[B], lc = ls[C], ld = ls[D];
     const int nca = NCART(la), ncb = NCART(lb), ncc = NCART(lc), ncd = NCART(ld);
     int ax[MAXCART], ay[MAXCART], az[MAXCART], bx[MAXCART], by[MAXCART], bz[MAXCART];
@@ -321,7 +332,7 @@ static void quartet(const EriCtx *c, int kab, int kcd, double *cart, double *t1,
     cart_components(lc, cx, cy, cz); cart_components(ld, dx, dy, dz);
     const int Lab = la + lb, Lcd = lc + ld, L = Lab + Lcd;
     memset(cart, 0, sizeof(double) * nca * ncb * ncc * ncd);
-    const int nab = nprim[A] * nprim[B], ncdp = nprim[C] * nprim[D];
+    const int nab = c->npp[kab], ncdp = c->npp[kcd];
     for (int iab = 0; iab < nab; ++iab) {
         const PrimPair *ab = &c->pairs[kab][iab];
         for (int icd = 0; icd < ncdp; ++icd) {
