@@ -48,7 +48,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tn(long G, int M, int N, in
                                                            double *__restrict__ C, int ldc, long strideC_batch,
                                                            long strideC_chunk,
                                                            const double *__restrict__ Dm = nullptr,
-                                                           double *__restrict__ vpart = nullptr)
+                                                           double *__restrict__ vpart = nullptr,
+                                                           int skip_lower = 0)
 {
     constexpr int THREADS = 64 * NW, CG = THREADS / 16;                  // 16 staging rows x CG column groups
     constexpr int BM = 64 * WGM, WGN = NW / WGM, NJ = WGM == 2 ? 4 : 2;   // wave tile 16 MI x 16 NJ
@@ -76,7 +77,21 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tn(long G, int M, int N, in
         batch = blockIdx.x / npair;
         ck = 0;
     }
-    const int a0 = (pair / nB) * BM, b0 = (pair % nB) * BN;
+    int a0 = (pair / nB) * BM, b0 = (pair % nB) * BN;
+    if (skip_lower) {
+        // C = A^T A (the exchange step): a tile whose rows all lie below its columns' block is the transpose
+        // of a tile that is computed, so only the others are enumerated (`npair` counts them; the skipped
+        // ones are filled in by k_mirror_lower after the slab sum).  Enumerated, not launched-and-exited:
+        // workgroups go to CUs round-robin, and dead ones would leave the same CUs idle in every round.
+        const int nA = (M + BM - 1) / BM;
+        int cnt = 0;
+        for (int ia = 0; ia < nA; ++ia)
+            for (int ib = 0; ib < nB; ++ib)
+                if (BM * ia < BN * ib + BN) {
+                    if (cnt == pair) { a0 = BM * ia; b0 = BN * ib; }
+                    ++cnt;
+                }
+    }
     const long glo = (long)ck * chunk, ghi = min(G, glo + chunk);
     A += batch * strideA;
     B += batch * strideB;
@@ -219,6 +234,15 @@ __global__ __launch_bounds__(256) void k_cd_dot(long n2, const double *__restric
         __syncthreads();
     }
     if (threadIdx.x == 0) v[blockIdx.x] = red[0];
+}
+
+// K[a][b] = K[b][a] for the tiles k_gemm_tn skipped (rows' 128-block entirely below the columns' 256-block)
+__global__ __launch_bounds__(256) void k_mirror_lower(int n, double *__restrict__ K)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)n * n) return;
+    const int a = (int)(e / n), b = (int)(e % n);
+    if ((a / 128) * 128 >= (b / CD_BN) * CD_BN + CD_BN) K[e] = K[(size_t)b * n + a];
 }
 
 // v[P] = sum_b vpart[P][b]: the per-b-block partials the half transform leaves (DOT), fixed order

@@ -354,7 +354,9 @@ void jk(XCSolver *s, int nao, const double *eri, const double *dm, double *J, do
 // total fills whole rounds of the chip best, with slabs <= 2 GB and >= 64 contraction rows per chunk
 long chunks_per_xcd(const XCSolver *s, int npair, long rows, size_t slab_bytes)
 {
-    long per_xcd = 1;
+    // the fewest chunks whose workgroup total fills at least 92 % of whole rounds of the chip (more
+    // chunks mean more slabs to sum and shorter contraction loops), else the best filling found
+    long best_c = 1;
     double best = 0.0;
     for (long c = 1; c <= 32; ++c) {
         const long wgs = 8L * npair * c;
@@ -362,9 +364,10 @@ long chunks_per_xcd(const XCSolver *s, int npair, long rows, size_t slab_bytes)
         if ((double)(8 * c) * (double)slab_bytes > 2.0e9 && c > 1) break;
         const long rounds = (wgs + s->num_cu - 1) / s->num_cu;
         const double eff = (double)wgs / (double)(rounds * s->num_cu);
-        if (eff > best + 1e-9) { best = eff; per_xcd = c; }
+        if (eff >= 0.92) return c;
+        if (eff > best + 1e-9) { best = eff; best_c = c; }
     }
-    return per_xcd;
+    return best_c;
 }
 
 // J and/or K from Cholesky vectors L (naux, nao, nao), D = dm, dm = cocc cocc^T with cocc (nao, nocc)
@@ -399,7 +402,10 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
         const int ldy = (nao + 1) & ~1;                   // even leading dimension of Yt: 16-byte rows
         const long G = (long)naux * nocc;                 // rows of Yt
         const int nA2 = (nao + 127) / 128, npair2 = nA2 * nB;
-        const long per_xcd = chunks_per_xcd(s, npair2, G, sizeof(double) * (size_t)n2);
+        int live2 = 0; // tiles of K = Yt^T Yt that are computed (the rest are mirrored)
+        for (int ia = 0; ia < nA2; ++ia)
+            for (int ib = 0; ib < nB; ++ib) live2 += !(128 * ia >= CD_BN * ib + CD_BN);
+        const long per_xcd = s->ksplit > 0 ? s->ksplit : chunks_per_xcd(s, live2, G, sizeof(double) * (size_t)n2);
         const int nslab = (int)(8 * per_xcd);
         long chunk = (G + nslab - 1) / nslab;
         chunk = ((chunk + CD_BK - 1) / CD_BK) * CD_BK;
@@ -437,10 +443,12 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
         {
             ScopedTimer t(s, "cd_k");
             // K = Yt^T Yt, split over the (P, i) rows
-            dim3 g((unsigned)(nslab * npair2));
+            dim3 g((unsigned)(nslab * live2));
             hipLaunchKernelGGL((k_gemm_tn<2, 4, true, true>), g, dim3(BG_THREADS), 0, st, G, nao, nao, ldy, ldy,
-                               yt, 0L, yt, 0L, chunk, nB, npair2, 1, kp, nao, 0L, n2, (const double *)nullptr, (double *)nullptr);
+                               yt, 0L, yt, 0L, chunk, nB, live2, 1, kp, nao, 0L, n2, (const double *)nullptr, (double *)nullptr, 1);
             hipLaunchKernelGGL(k_sum_slabs8, dim3((unsigned)((n2 + 31) / 32)), dim3(256), 0, st, (size_t)n2, nslab, (size_t)n2, kp, K);
+            if (live2 < npair2)
+                hipLaunchKernelGGL(k_mirror_lower, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, nao, K);
         }
     }
     if (J) {
