@@ -175,8 +175,9 @@ def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=9):
 
 def k_build_mfma(lib_path, dev, nao=494, nocc=47, naux=3000, reps=5):
     """Exact-exchange build on the fp64 matrix cores (north_star (d)): DFT_ComputeJKFactorized on synthetic
-    Cholesky vectors of the Anthracene/def2-TZVP shape (dense ERI there: 476 GB).  Useful flops
-    4 naux nao^2 nocc (half transform + Yt^T Yt), kernel times from HIP events inside the library."""
+    Cholesky vectors of the Anthracene/def2-TZVP shape (dense ERI there: 476 GB).  Algorithmic flops:
+    2 naux nao^2 nocc for the half transform + naux nocc nao (nao+1) for K = Yt^T Yt as a symmetric
+    rank-k update (the kernel mirrors the lower tiles); kernel times from HIP events inside the library."""
     g = torch.Generator(device=dev); g.manual_seed(SEED)
     L = torch.randn((naux, nao, nao), dtype=torch.float64, device=dev, generator=g) * 0.1
     c = torch.randn((nao, nocc), dtype=torch.float64, device=dev, generator=g)
@@ -191,14 +192,17 @@ def k_build_mfma(lib_path, dev, nao=494, nocc=47, naux=3000, reps=5):
         if it >= 2:
             for k, v in s.timings():
                 acc[k] = acc.get(k, 0.0) + v / reps
-    fl = 2.0 * naux * nao * nao * nocc
+    fl_half = 2.0 * naux * nao * nao * nocc                 # Yt_P = Cocc^T L_P
+    fl_syrk = 1.0 * naux * nocc * nao * (nao + 1)           # K = Yt^T Yt counted as a symmetric rank-k update
     t_k = acc["cd_half"] + acc["cd_k"]
     del L, s
     torch.cuda.empty_cache()
     return {"workload": f"anthracene_b3lyp_def2tzvp shape: nao={nao} nocc={nocc} naux={naux} synthetic Cholesky vectors "
                         f"({8.0 * naux * nao * nao / 1e9:.2f} GB resident)",
-            "kernels_ms": acc, "k_ms": t_k, "flops": 2 * fl,
-            "achieved": 2 * fl / t_k / 1e9, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": 2 * fl / t_k / 1e9 / F64_MFMA_PEAK_TF,
+            "kernels_ms": acc, "k_ms": t_k, "flops": fl_half + fl_syrk,
+            "achieved": (fl_half + fl_syrk) / t_k / 1e9, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": (fl_half + fl_syrk) / t_k / 1e9 / F64_MFMA_PEAK_TF,
+            "full_square_equivalent_tflops": 2 * fl_half / t_k / 1e9,
             "j_pass_gbs": 8.0 * naux * nao * nao / acc["cd_j"] / 1e6}
 
 
