@@ -2,6 +2,8 @@
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 import quantum_compute_dft_amd as q
+from quantum_compute_dft_amd.hostinfo import blas_threads
+_pin = blas_threads(); _pin.__enter__()   # host pools on the CPU share (hostinfo.py): no quota-throttling stalls in the timings
 dev = torch.device('cuda:0')
 nocc = 47
 for nao in (128, 256, 384, 512, 768, 1024):

@@ -2,6 +2,8 @@
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 import quantum_compute_dft_amd as q
+from quantum_compute_dft_amd.hostinfo import blas_threads
+_pin = blas_threads(); _pin.__enter__()   # host pools on the CPU share (hostinfo.py): no quota-throttling stalls in the timings
 dev = torch.device('cuda:0')
 cases = [("benzene def2-SVP", 114, 21, 900), ("anthracene def2-SVP", 246, 47, 1900), ("anthracene def2-TZVP", 494, 47, 3000),
          ("C33 def2-SVP (1/8 of the vectors)", 1150, 250, 1000)]

@@ -4,6 +4,8 @@ import sys, time, numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import oracle
 import quantum_compute_dft_amd as q
+from quantum_compute_dft_amd.hostinfo import blas_threads
+_pin = blas_threads(); _pin.__enter__()   # host pools on the CPU share (hostinfo.py): no quota-throttling stalls in the timings
 from quantum_compute_dft_amd import basis
 from helpers import synth_inputs
 dev = torch.device('cuda:0')
