@@ -102,6 +102,34 @@ def test_alternative_kernel_paths_match_oracle(dev, xc_type, path):
         _check(exc, v, exc_ref, v_ref)
 
 
+@pytest.mark.parametrize("opt,val", [("rho_rows", 128), ("rho_rows", 64), ("ksplit", 3)])
+def test_large_basis_kernel_options_match_oracle(dev, opt, val):
+    """nao > 128 takes the tiled kernels: both density tilings (64-row two-per-CU, 128-row) and a forced
+    chunk count of the Vxc split give the oracle's numbers."""
+    dm, ao, gr, w = synth_inputs(700, 150, seed=55)
+    exc_ref, v_ref = oracle.compute_xc(2, dm, ao, w, gr)
+    exc, v = _run(_solver(2, **{opt: val}), dm, ao, gr, w, dev)
+    _check(exc, v, exc_ref, v_ref)
+
+
+@pytest.mark.parametrize("pt", [0, 8, 16])
+def test_eval_ao_tile_heights_agree_bitwise(dev, pt):
+    syms, xyz = basis.parse_xyz("C 0 0 0; O 1.1 0.2 0; H -0.6 0.8 0.3; N 0.3 -1.2 0.4")
+    sh = basis.build_shells(syms, xyz, "def2-svp")
+    rng = np.random.default_rng(11)
+    ngrid = 1003
+    d_c = torch.as_tensor(rng.uniform(-5, 5, (ngrid, 3)), device=dev)
+    outs = []
+    for p in (pt, 16):
+        w = _solver(1, ao_pt=p)
+        d_ao = torch.zeros((ngrid, sh.nao), dtype=torch.float64, device=dev)
+        d_gr = torch.zeros((3, ngrid, sh.nao), dtype=torch.float64, device=dev)
+        assert w.eval_ao(sh, d_c, ngrid, d_ao, d_gr) == 0
+        torch.cuda.synchronize()
+        outs.append((d_ao.clone(), d_gr.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_unaligned_base_pointers(dev):
     # a view that starts 8 bytes into an allocation: the 16-byte load form must not be used
     ngrid, nao = 1000, 30
