@@ -21,9 +21,9 @@ def main(argv=None):
     p.add_argument("--eri", default="dense", choices=["dense", "cholesky"],
                    help="dense: the nao^4 tensor of grid.py:65; cholesky: factorised J/K (large basis sets)")
     p.add_argument("--chol-tol", type=float, default=1e-9)
-    p.add_argument("--eigensolver", default="auto", choices=["auto", "exact", "subspace"],
-                   help="exact: eigh(F, S) every cycle as dft.py:227; subspace: warm-started Chebyshev-filtered subspace "
-                        "iteration with exact fallback; auto: subspace from 400 basis functions on")
+    p.add_argument("--eigensolver", default="auto", choices=["auto", "exact", "refine", "subspace"],
+                   help="exact/auto: eigh(F, S) every cycle as dft.py:227; refine: refinement of the previous cycle's "
+                        "eigenvectors on the GPU, subspace: filtered subspace iteration (experiments, full solver as fallback)")
     p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 (nccl = RCCL)")
     args = p.parse_args(argv)
 
@@ -74,7 +74,9 @@ def main(argv=None):
         print(f"Median per cycle after the first: XC {res['xc_ms']:.4f} ms, J/K {res['jk_ms']:.4f} ms ({args.eri} ERI), "
               f"whole SCF iteration {res['iter_ms']:.4f} ms ({res['cycles']} cycles)")
         st = getattr(backend.eigh, "stats", None)
-        if st:
+        if st and "refined" in st:
+            print(f"Eigensolver: {st['refined']} cycles by refinement of the previous eigenvectors ({st['steps']} steps), {st['exact']} by full diagonalisation")
+        elif st:
             print(f"Eigensolver: {st['subspace']} cycles by filtered subspace iteration ({st['passes']} filter passes), {st['exact']} by full diagonalisation")
         print("-" * 80)
     else:

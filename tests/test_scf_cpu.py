@@ -1,5 +1,6 @@
 """The SCF loop (dft.py:181-266 contract) on the CPU oracle backend: plumbing of inputs -> loop."""
 import numpy as np
+from scipy.linalg import eigh
 import pytest
 
 from quantum_compute_dft_amd import inputs, scf
@@ -54,3 +55,19 @@ def test_subspace_eigensolver_reproduces_the_exact_scf():
     # the returned orbitals are S-orthonormal and diagonalise the last Fock matrix on their span
     e, C = be.eigh.theta.numpy(), None
     assert np.all(np.diff(e) >= -1e-12)
+
+
+def test_refined_eigensolver_reproduces_the_exact_scf():
+    """scf.RefinedDiagonaliser (Ogita-Aishima refinement of the previous cycle's eigenvectors, full solver
+    as fallback) in place of eigh(F, S): same cycle count, energy, density and orbital energies."""
+    inp = inputs.build("H2O", "def2-svp", 1, verbose=False)
+    kw = dict(log=None, conv_e=1e-10, conv_dm=1e-8)
+    r0 = scf.run_scf(inp, OracleBackend(inp, "B3LYP"), "B3LYP", **kw)
+    be = OracleBackend(inp, "B3LYP")
+    be.eigh = scf.RefinedDiagonaliser(inp.S, inp.nocc, lambda F: eigh(F, inp.S))
+    r1 = scf.run_scf(inp, be, "B3LYP", **kw)
+    assert r0["converged"] and r1["converged"] and r1["cycles"] == r0["cycles"]
+    assert r1["E_tot"] == pytest.approx(r0["E_tot"], abs=1e-10)
+    assert np.abs(r1["dm"] - r0["dm"]).max() < 1e-9
+    assert np.abs(r1["mo_energy"] - r0["mo_energy"]).max() < 1e-9
+    assert be.eigh.stats["refined"] >= 5 and be.eigh.stats["exact"] >= 1
