@@ -115,19 +115,19 @@ class RefinedDiagonaliser:
     on 16 host cores, against 6.2 ms for the XC sweep); a refinement step costs ~0.15 ms there.
 
     Pairs whose first-order rotation would exceed 1/3 (near-degenerate orbitals, e.g. Benzene's e pairs)
-    only get their orthonormality part: their mutual rotation is irrelevant to the density matrix as long
-    as both lie on one side of the gap, and that is checked -- an occupied-virtual pair left in that state,
+    get their orthonormality part and an exact 2x2 rotation instead; their mutual rotation is irrelevant to
+    the density matrix as long as both lie on one side of the gap, and that is checked -- an
+    occupied-virtual pair left in that state,
     a first step above 0.25, a step that does not contract by 0.3, or `max_it` steps without reaching `tol`
     all hand the matrix to the full solver (`exact`), which also does the first cycle.  Returns all n
     orbitals sorted by energy, like eigh.
 
     OPT-IN (`--eigensolver refine`).  It reproduces the exact loop to 1e-12 Ha with the same cycle count
-    (tests/test_scf_cpu.py), but as it stands it does not pay on MI355X: the unresolved near-degenerate
-    pairs make the tail of the iteration linear, so only the late cycles succeed (Benzene/def2-SVP 8 of
-    16 cycles, Anthracene/def2-SVP 3 of 24), each step is ~15 small launches and two host syncs (~0.1 ms
-    at n = 114), and the failed attempts are paid on top of the full solve: 2.04 against 1.42 ms per cycle
-    (Benzene), 7.44 against 7.03 ms (Anthracene/def2-SVP).  Resolving the near-degenerate clusters exactly
-    is what it needs."""
+    (tests/test_scf_cpu.py), but as it stands it does not pay on MI355X: only the later half of the cycles
+    moves little enough to converge (Benzene/def2-SVP 8 of 16 cycles; Anthracene/def2-SVP, whose virtual
+    spectrum is dense, 4 of 24), each step is ~15 small launches and two host syncs
+    (~0.1 ms at n = 114), and the failed attempts are paid on top of the full solve: 2.04 against 1.42 ms
+    per cycle (Benzene), 7.6 against 7.0 ms (Anthracene/def2-SVP).  See DESIGN.md section 8."""
 
     def __init__(self, S, nocc, exact, device=None, tol=1e-10, max_it=6):
         import torch
@@ -152,15 +152,24 @@ class RefinedDiagonaliser:
             num = S + lam[None, :] * R
             far = diff.abs() > 3.0 * num.abs() + 1e-10          # first-order rotation stays below 1/3
             far.fill_diagonal_(False)
-            E = t.where(far, num / t.where(far, diff, t.ones_like(diff)), 0.5 * R)
+            # the other pairs (near-degenerate orbitals): orthonormality part, plus -- where they are really
+            # coupled -- the exact 2x2 rotation that zeroes S_ij (tan 2 theta = 2 S_ij / (S_jj - S_ii), small
+            # branch); left coupled they make the convergence of every pair they touch linear
+            coupled = (~far) & (S.abs() > 1e-12 * float(lam.abs().max()))
+            coupled.fill_diagonal_(False)
+            theta = 0.5 * t.atan2(2.0 * S, diff)
+            theta = t.where(theta > np.pi / 4, theta - np.pi / 2, theta)
+            theta = t.where(theta < -np.pi / 4, theta + np.pi / 2, theta)
+            EJ = t.where(coupled, t.sin(theta), t.zeros_like(S))
+            E = t.where(far, num / t.where(far, diff, t.ones_like(diff)), 0.5 * R + EJ)
             # occupied-virtual pairs must all be resolved: a coupled pair left "near" across the gap is a failure
             occ = t.zeros(self.n, dtype=t.bool, device=self.dev)
             occ[t.argsort(lam)[:self.nocc]] = True
             across = occ[:, None] != occ[None, :]
             stuck = bool(((~far) & across & (num.abs() > 1e-9)).any())
-            emax = float(E.abs().max())
+            emax = float(t.where(coupled, t.zeros_like(E), E).abs().max())   # rotations inside a cluster are free
             self.stats["steps"] += 1
-            if stuck or emax > 0.25 or (prev is not None and emax > 0.3 * prev):
+            if stuck or emax > 0.25 or (prev is not None and emax > 0.3 * prev and emax > 1e-9):
                 return None, None
             X = X + X @ E
             if emax < self.tol:
