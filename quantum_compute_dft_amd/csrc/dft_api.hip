@@ -52,6 +52,7 @@ struct XCSolver {
     int profile = 0;
     int ksplit = 0;
     int ao_pt = 0; // grid points per workgroup of the AO kernel: 0 auto, 8 or 16
+    int fuse_finish = 1; // the Vxc reduce kernel's last block also finishes Exc (one launch fewer)
     int rho_rows = 64; // grid rows per workgroup of the large-basis rho kernel: 64 (two workgroups per CU) or 128
     // workspace
     DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells, msym, cdy, cdc, cdv;
@@ -209,7 +210,11 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
         !reserve(s, s->slabs, sizeof(double) * (size_t)nslab * nao * nao, "hipMalloc(slabs)") ||
         false)
         return false;
-    if (!reserve(s, s->exc, sizeof(double), "hipMalloc(exc)")) return false;
+    { // [Exc | ticket of the finishing reduce kernel]: the ticket starts at 0 and every call leaves it at 0
+        const bool fresh = s->exc.cap == 0;
+        if (!reserve(s, s->exc, 2 * sizeof(double), "hipMalloc(exc)")) return false;
+        if (fresh && !hip_ok(s, hipMemsetAsync(s->exc.p, 0, 2 * sizeof(double), s->stream), "memset(exc)")) return false;
+    }
     if (gga && (!reserve(s, s->sigma, sizeof(double) * ng, "hipMalloc(sigma)") ||
                 !reserve(s, s->grad, sizeof(double) * 3 * ng, "hipMalloc(grad)")))
         return false;
@@ -305,7 +310,12 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
             hipLaunchKernelGGL(k_symmetrize, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, nao, M, vxc);
         } else if (b3 && !fast) {
             hipLaunchKernelGGL(k_reduce_slabs8<true>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
-        } else { // wave-specialised slabs are already symmetrised for B3LYP
+        } else if (s->fuse_finish) { // wave-specialised slabs are already symmetrised for B3LYP
+            // last launch of the call: its last-ticket block also finishes Exc (device scalar + host-mapped word)
+            hipLaunchKernelGGL((k_reduce_slabs8<false, true>), g, dim3(256), 0, st, nao, nslab, slabs, vxc, nxb, partial, exc,
+                               want_host_exc ? s->h_exc_dev : nullptr, (unsigned *)(exc + 1));
+            return hip_ok(s, hipGetLastError(), "XC sweep launch");
+        } else {
             hipLaunchKernelGGL(k_reduce_slabs8<false>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
         }
         // last launch of the call: Exc to the device scalar and to host-mapped memory
@@ -699,6 +709,7 @@ int DFT_SetOption(XCSolver *s, const char *key, double value)
     if (!strcmp(key, "path")) { s->path = (int)value; return 0; }
     if (!strcmp(key, "profile")) { s->profile = value != 0.0; return 0; }
     if (!strcmp(key, "spin_wait")) { s->spin_wait = value != 0.0; return 0; }
+    if (!strcmp(key, "fuse_finish")) { s->fuse_finish = value != 0.0; return 0; }
     if (!strcmp(key, "rho_rows")) { s->rho_rows = value == 128.0 ? 128 : 64; return 0; }
     if (!strcmp(key, "ao_pt")) { s->ao_pt = value == 16.0 ? 16 : value == 8.0 ? 8 : 0; return 0; }
     if (!strcmp(key, "ksplit")) { s->ksplit = value > 0 ? (int)value : 0; return 0; }

@@ -533,10 +533,19 @@ __global__ __launch_bounds__(256) void k_finish_exc(long npart, const double *__
 // slab groups per block, then a fixed tree over the groups.  SYM adds the transpose with
 // transposed reads (validation path only; the production paths symmetrise in-kernel or with
 // k_symmetrize).
-template <bool SYM>
+// FIN: the block that draws the last ticket also does k_finish_exc's job (fixed-order sum of the Exc
+// partials -> device scalar and host-mapped word), saving that launch and its dispatch gap (~7 us of a
+// 286 us call).  No fence goes with the ticket: the partials come from an earlier kernel, and everything a
+// caller does with V afterwards is ordered behind this kernel by the stream -- the host-mapped word only
+// says "Exc is final", which is all DFT_ComputeXC returns.  (The per-block device-scope __threadfence() of a
+// first attempt cost 10-30 us: every block's L2 write-back request queues at the L2.)
+template <bool SYM, bool FIN = false>
 __global__ __launch_bounds__(256) void k_reduce_slabs8(int nao, int nslab,
                                                        const double *__restrict__ slabs,
-                                                       double *__restrict__ V)
+                                                       double *__restrict__ V,
+                                                       long npart = 0, const double *__restrict__ partial = nullptr,
+                                                       double *__restrict__ exc_dev = nullptr, double *exc_host = nullptr,
+                                                       unsigned *ticket = nullptr)
 {
     __shared__ double part[256];
     const size_t n2 = (size_t)nao * nao;
@@ -558,6 +567,30 @@ __global__ __launch_bounds__(256) void k_reduce_slabs8(int nao, int nslab,
     if (grp == 0 && e < n2) {
         const double *p = &part[el];
         V[e] = ((p[0] + p[32]) + (p[64] + p[96])) + ((p[128] + p[160]) + (p[192] + p[224]));
+    }
+    if (FIN) {
+        __shared__ int last;
+        __syncthreads();
+        if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+        __syncthreads();
+        if (last) {
+            double x = 0.0;
+            for (long i = threadIdx.x; i < npart; i += 256) x += partial[i];
+            part[threadIdx.x] = x;
+            __syncthreads();
+            for (int m = 128; m >= 1; m >>= 1) {
+                if ((int)threadIdx.x < m) part[threadIdx.x] += part[threadIdx.x + m];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                *ticket = 0; // ready for the next call on this solver
+                exc_dev[0] = part[0];
+                if (exc_host) {
+                    *(volatile double *)exc_host = part[0];
+                    __threadfence_system();
+                }
+            }
+        }
     }
 }
 
