@@ -17,7 +17,7 @@ step() { # name timeout cmd...
 [ -z "$SKIP_BENCH" ] && step bench 600 python bench.py ${BENCH_ARGS:-}
 if [ -n "$DO_PROF" ]; then
   export TMPDIR=/tmp
-  step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$PWD/$OUT/prof" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline ${BENCH_ARGS:-}
+  step rocprof 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$PWD/$OUT/prof" -- python3 bench.py --no-cpu-baseline ${BENCH_ARGS:-}
   find $OUT/prof -name "*kernel_stats.csv" | head -3
 fi
 echo "=== done"
