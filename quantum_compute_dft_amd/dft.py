@@ -18,8 +18,8 @@ def main(argv=None):
     p.add_argument("--grid-level", type=int, default=3)   # grid.py:59
     p.add_argument("--quirks", type=int, default=1, help="1: reference formulas as shipped; 0: corrected VWN5/PBE-c derivatives")
     p.add_argument("--lib", default=None, help="path of libdft.so")
-    p.add_argument("--eri", default="dense", choices=["dense", "cholesky"],
-                   help="dense: the nao^4 tensor of grid.py:65; cholesky: factorised J/K (large basis sets)")
+    p.add_argument("--eri", default="auto", choices=["auto", "dense", "cholesky"],
+                   help="dense: the nao^4 tensor of grid.py:65; cholesky: factorised J/K; auto: dense while it stays below 8 GB (nao <= 178)")
     p.add_argument("--chol-tol", type=float, default=1e-9)
     p.add_argument("--eigensolver", default="auto", choices=["auto", "exact", "refine", "subspace"],
                    help="exact/auto: eigh(F, S) every cycle as dft.py:227; refine: refinement of the previous cycle's "
@@ -50,6 +50,10 @@ def main(argv=None):
     _pool_pin.__enter__()
     print(f"=== DFT Solver: {args.functional} | Molecule: {atom_file} ===")
     print("Building CPU data...")
+    if args.eri == "auto":
+        from . import basis as _basis
+        _nao = _basis.build_shells(*_basis.parse_xyz(atom_path), args.basis).nao
+        args.eri = "dense" if 8.0 * _nao ** 4 <= 8.0e9 else "cholesky"
     inp = inputs.build(atom_path, args.basis, args.grid_level, device=device, eri_mode=args.eri, chol_tol=args.chol_tol)
     print(f"System Info: NAO={inp.shells.nao}, Grid={inp.grids.size}, Occupied={inp.nocc}")
     print(f"Calculating AO Gradients ({args.functional} mode)..." if args.functional != "LDA" else "Skipping AO Gradients (LDA mode).")
