@@ -289,15 +289,16 @@ def main():
     # per call for the first 10 ms after idle, 243-248 us from 40 ms on), so an idle-start measurement of a
     # few ms quotes the ramp, not the engine.  Untimed, like the warm-up steps that follow.
     t_spin = time.perf_counter() + args.spinup_ms * 1e-3
-    while time.perf_counter() < t_spin:
+    while True:
         for _ in range(8):
             exc = step()
-        if world > 1:   # every rank must run the same number of (collective) steps: stop together
-            go = torch.tensor([1.0 if time.perf_counter() < t_spin else 0.0], dtype=torch.float64,
-                              device=dev if args.backend == "nccl" else "cpu")
-            dist.all_reduce(go, op=dist.ReduceOp.MIN)
-            if float(go.item()) == 0.0:
-                break
+        go = 1.0 if time.perf_counter() < t_spin else 0.0
+        if world > 1:   # every rank must run the same number of (collective) steps: the decision is collective too
+            flag = torch.tensor([go], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            go = float(flag.item())
+        if go == 0.0:
+            break
     for _ in range(args.warmup):
         exc = step()
     fence()
