@@ -1,16 +1,27 @@
 #!/usr/bin/env python3
 """Benchmark of the XC sweep (DFT_ComputeXC) on MI355X.
 
-python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+python bench.py --gpus N --steps K --warmup W
+
+N > 1 started as a plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) launches its own
+N rank processes -- a `python -m torch.distributed.run` child on 127.0.0.1, started BEFORE anything in
+this process touches the GPU -- and exits with the child's code; started by torch.distributed.run itself
+it is one of the ranks.  One process per GPU, RCCL ("nccl") over xGMI.
 
 Step   = one DFT_ComputeXC call on one batch of synthetic AO/grid data resident in HBM
          (the bracket the reference times at dft.py:205-208: call + device sync), followed for
          N>1 by the RCCL all-reduce of [Vxc | Exc] over the grid shards.
 Work   = BASELINE.json's metric config: Benzene GGA(PBE) def2-SVP shape (nao 114, ngrid 143 556)
-         per GPU (weak scaling: every rank owns a full-size grid shard).
-Output = ONE JSON line on rank 0 (metric grid-points/s) carrying `roofline` for the dominant
-         kernel (HIP-event timed on the solver's stream) and `cpu_baseline` (the OpenMP build of
-         the CPU oracle timed on a bounded slice of the same inputs; N=1, rank 0 only).
+         per GPU (weak scaling: every rank owns a full-size grid shard).  `--scaling strong` shards ONE
+         molecule's grid over the ranks instead (default there: BASELINE config 5, C33H56N7O17P3S
+         B3LYP/def2-SVP, nao 1150, 1 436 406 points / N); the default run carries the same measurement
+         as the `strong_config5` object so one driver invocation per N yields both curves.
+Output = ONE JSON line on rank 0 (metric grid-points/s).  `roofline` is the WHOLE call against SURVEY
+         8(d)'s algorithmic bytes/flops (its `dominant_kernel` member is the single-kernel figure, HIP
+         events on the solver's stream); `cpu_baseline` is the prebuilt OpenMP CPU oracle timed on a
+         bounded slice of the same inputs (N=1, rank 0 only); `ao_sweep` the AO-on-grid kernel on
+         Benzene/def2-SVP's real shells and level-3 grid; `scf_iteration*` one SCF cycle at the Benzene
+         GGA and Anthracene B3LYP shapes; `k_build` the factorised exact exchange on the fp64 matrix cores.
 """
 import argparse
 import glob
@@ -79,8 +90,7 @@ def cpu_baseline(xc, dm, ao, gr, w, target_seconds):
     dft_solver.cu:294-432 + B^T.AO) timed on a bounded slice of the same inputs."""
     import oracle                                   # test infrastructure: the checker, timed as the baseline
     threads = host_cpu_share()
-    os.environ["OMP_NUM_THREADS"] = str(threads)
-    oracle.build(omp=True)
+    os.environ["OMP_NUM_THREADS"] = str(threads)    # the prebuilt OpenMP checker is loaded, never compiled here
     t = {"LDA": 0, "GGA": 1, "B3LYP": 2}[xc]
     ngrid = ao.shape[0]
 
@@ -206,18 +216,130 @@ def k_build_mfma(lib_path, dev, nao=494, nocc=47, naux=3000, reps=5):
             "j_pass_gbs": 8.0 * naux * nao * nao / acc["cd_j"] / 1e6}
 
 
-def pmc_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled
-    per the gfx950 correction, + WRITE_SIZE); None when no profile matches this workload."""
+def pmc_traffic(workload, kernels):
+    """HBM bytes per DFT_ComputeXC call from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
+    the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE), summed over the kernels of the call that
+    the newest matching profile lists; None when no profile matches this workload and kernel set."""
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if d.get("workload") == workload and kernel in d.get("kernels", {}):
-            best = {"hbm_bytes": d["kernels"][kernel]["hbm_bytes"], "source": os.path.basename(f)}
+        have = d.get("kernels", {})
+        if d.get("workload") == workload and all(k in have for k in kernels):
+            best = {"per_kernel": {k: have[k]["hbm_bytes"] for k in kernels}, "source": os.path.basename(f)}
     return best
+
+
+def ao_sweep_leg(lib_path, dev, reps=6, burst=10):
+    """North-star kernel (a): DFT_EvalAO (values + gradients, grid.py:30-31,38) on Benzene/def2-SVP's real
+    shell table and its real level-3 grid.  Algorithmic bytes ngrid*(8*nao*4 + 32): the
+    kernel is HBM-write bound.  HIP events recorded by the library around the launch; also the chained
+    AO -> rho -> Vxc rate (DFT_EvalAO + DFT_ComputeXC per step, wall clock)."""
+    from quantum_compute_dft_amd import basis, grid_gen, inputs
+    syms, xyz = basis.parse_xyz(os.path.join(inputs.DATA_DIR, "Benzene.xyz"))
+    sh = basis.build_shells(syms, xyz, "def2-svp")
+    grids = grid_gen.Grids(syms, xyz, level=3, device=dev)
+    ngrid, nao = grids.size, sh.nao
+    d_c = torch.as_tensor(grids.coords, device=dev)
+    d_w = torch.as_tensor(grids.weights, device=dev)
+    d_ao = torch.empty((ngrid, nao), dtype=torch.float64, device=dev)
+    d_gr = torch.empty((3, ngrid, nao), dtype=torch.float64, device=dev)
+    s = q.DFTSolverWrapper(lib_path, "GGA")
+    s.set_option("profile", 1)
+    ms = []
+    for r in range(reps + 1):
+        for _ in range(burst):
+            s.eval_ao(sh, d_c, ngrid, d_ao, d_gr)
+        t = dict(s.timings())["eval_ao"]                 # the burst's last launch
+        if r:
+            ms.append(t)
+    t_ao = float(np.mean(ms))
+    s.set_option("profile", 0)
+    g = torch.Generator(device=dev); g.manual_seed(SEED)
+    C = 0.3 * torch.randn((nao, 21), dtype=torch.float64, device=dev, generator=g)
+    dm = (2.0 * C @ C.T).contiguous()
+    d_v = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
+    for _ in range(5):
+        s.eval_ao(sh, d_c, ngrid, d_ao, d_gr); s.compute_xc(ngrid, nao, dm, d_ao, d_w, d_v, d_gr)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 30
+    for _ in range(n):
+        s.eval_ao(sh, d_c, ngrid, d_ao, d_gr)
+        exc = s.compute_xc(ngrid, nao, dm, d_ao, d_w, d_v, d_gr)
+    torch.cuda.synchronize(); t_chain = (time.perf_counter() - t0) / n
+    b_alg = ngrid * (8.0 * nao * 4 + 32)
+    nelec = float((d_w * ((d_ao @ dm) * d_ao).sum(1)).sum())
+    return {"workload": f"DFT_EvalAO deriv 1, Benzene/def2-SVP real shells ({len(sh.l)} shells, nao {nao}) on its level-3 grid ({ngrid} points)",
+            "kernel_ms": t_ao, "alg_bytes": b_alg, "bound": "hbm", "achieved": b_alg / t_ao / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": b_alg / t_ao / 1e6 / HBM_PEAK_GBS,
+            "chained_ao_rho_vxc": {"ms_per_step": 1e3 * t_chain, "grid_points_per_sec": ngrid / t_chain,
+                                   "exc": exc, "integral_rho": nelec,
+                                   "note": "DFT_EvalAO + DFT_ComputeXC(GGA) per step on the real AO values, synthetic PSD density matrix"}}
+
+
+def strong_leg(lib_path, dev, dist, backend, world, rank, workload, steps=6, warmup=2):
+    """ONE molecule's grid sharded over the ranks (BASELINE config 5): rank r keeps block
+    grid_shard.shard_bounds(ngrid, world, r) resident, a step is the local sweep + ONE all-reduce of
+    [Vxc | Exc] (nao^2+1 doubles).  Per step the sweep and the collective are bracketed separately
+    (device sync between them) so the payload's time is reported next to its size."""
+    from quantum_compute_dft_amd.grid_shard import shard_bounds
+    xc, nao, ngrid = WORKLOADS[workload]
+    lo, hi = shard_bounds(ngrid, world, rank)
+    n_loc = hi - lo
+    dm, ao, gr, w = synth(max(n_loc, 16), nao, xc != "LDA", dev, SEED + 7919 * (rank + 1))
+    if world > 1:
+        if backend == "nccl":
+            dist.broadcast(dm, 0)
+        else:
+            h = dm.cpu(); dist.broadcast(h, 0); dm.copy_(h)
+    solver = q.DFTSolverWrapper(lib_path, xc)
+    out = torch.zeros(nao * nao + 1, dtype=torch.float64, device=dev)
+    d_v, d_e = out[: nao * nao], out[nao * nao:]
+    rows = []
+    for it in range(warmup + steps):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        if n_loc:
+            solver.compute_xc_async(n_loc, nao, dm, ao, w, d_v, d_e, gr)
+        else:
+            out.zero_()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        if world > 1:
+            if backend == "nccl":
+                dist.all_reduce(out)
+            else:
+                h = out.cpu(); dist.all_reduce(h); out.copy_(h)
+        exc = float(d_e.item()); t2 = time.perf_counter()
+        if it >= warmup:
+            rows.append((t1 - t0, t2 - t1, t2 - t0))
+    t = torch.tensor(rows, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # slowest rank per step
+    med = t.median(dim=0).values.tolist()
+    del ao, gr, w, solver
+    torch.cuda.empty_cache()
+    b_alg, f_alg = kernel_model("xc_sweep", xc, ngrid, nao)
+    return {"workload": f"{workload}: ONE grid of {ngrid} points sharded over {world} GPU(s) ({n_loc} on rank 0), nao {nao}, {xc}",
+            "scaling": "strong", "ms_per_step": 1e3 * med[2], "sweep_ms": 1e3 * med[0], "allreduce_ms": 1e3 * med[1],
+            "allreduce_payload_bytes": 8 * (nao * nao + 1), "grid_points_per_sec": ngrid / med[2],
+            "steps": steps, "statistic": "median over steps of the max over ranks", "exc": exc,
+            "hbm_frac": b_alg / med[2] / 1e9 / HBM_PEAK_GBS, "mfma_frac": f_alg / med[2] / 1e12 / F64_MFMA_PEAK_TF}
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a torch.distributed.run child
+    (fresh processes; this one has not touched the GPU and never does) and leave with its exit code."""
+    import socket
+    import subprocess
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL, shared tensors)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -226,13 +348,19 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--spinup-ms", type=float, default=80.0, help="untimed sustained load before the warm-up steps (GPU clock ramp)")
-    ap.add_argument("--workload", default="benzene_gga_def2svp", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank owns a full-size grid (default, the BASELINE metric); strong: one grid sharded over the ranks")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-k-build", action="store_true", help="skip the factorised exact-exchange (fp64 MFMA) measurement")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip ao_sweep / scf_iteration / strong_config5 (kernel iteration runs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo only to rehearse N>1 on a single card")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     # Host BLAS/OpenMP pools on the CPU share from the first numpy call on: left at one thread per
     # visible core (256), the workers of a single BLAS call spin long enough after it to exhaust the
@@ -244,8 +372,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or under torch.distributed.run with N ranks")
+    lib_path = q.library_path()                          # never compiles: __graft_entry__.build() did
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     ndev = torch.cuda.device_count()
     dev_index = local if args.backend == "nccl" else local % max(1, ndev)
@@ -259,21 +388,33 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    xc, nao, ngrid = WORKLOADS[args.workload]
-    dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)   # dm identical on all ranks
+    strong = args.scaling == "strong"
+    workload = args.workload or ("c33_b3lyp_def2svp" if strong else "benzene_gga_def2svp")
+    xc, nao, ngrid_all = WORKLOADS[workload]
+    if strong:
+        from quantum_compute_dft_amd.grid_shard import shard_bounds
+        lo, hi = shard_bounds(ngrid_all, world, rank)
+        ngrid = hi - lo
+        total_points = ngrid_all
+    else:
+        ngrid, total_points = ngrid_all, world * ngrid_all
+    dm, ao, gr, w = synth(max(ngrid, 16), nao, xc != "LDA", dev, SEED + rank)   # dm identical on all ranks
     if world > 1:
         if args.backend == "nccl":
             dist.broadcast(dm, 0)
         else:
             h = dm.cpu(); dist.broadcast(h, 0); dm.copy_(h)
-    solver = q.DFTSolverWrapper(q.build_library(), xc)
+    solver = q.DFTSolverWrapper(lib_path, xc)
     out = torch.zeros(nao * nao + 1, dtype=torch.float64, device=dev)   # [Vxc | Exc]
     d_v, d_e = out[: nao * nao], out[nao * nao:]
 
     def step():
         if world == 1:
             return solver.compute_xc(ngrid, nao, dm, ao, w, d_v, gr)    # synchronous, returns Exc
-        solver.compute_xc_async(ngrid, nao, dm, ao, w, d_v, d_e, gr)
+        if ngrid:
+            solver.compute_xc_async(ngrid, nao, dm, ao, w, d_v, d_e, gr)
+        else:
+            out.zero_()
         if args.backend == "nccl":
             dist.all_reduce(out)                                        # sum of the shard partials
         else:                                                           # rehearsal: gloo reduces on the host
@@ -313,57 +454,81 @@ def main():
         dt = float(tt.item())
 
     # per-kernel durations: HIP events recorded by the library on its own stream, same steps
-    solver.set_option("profile", 1)
-    acc = {}
-    for i in range(max(args.steps, 10)):
-        solver.compute_xc(ngrid, nao, dm, ao, w, d_v, gr)
-        if i % 10 == 9:   # events are recorded on every call; read every tenth so the calls stay back to back
-            for name, ms in solver.timings():
-                acc.setdefault(name, []).append(ms)
-    solver.set_option("profile", 0)
-    kern = {k: float(np.mean(v)) for k, v in acc.items()}
+    kern = {}
+    if ngrid:
+        solver.set_option("profile", 1)
+        acc = {}
+        for i in range(max(args.steps, 10)):
+            solver.compute_xc(ngrid, nao, dm, ao, w, d_v, gr)
+            if i % 10 == 9:   # events are recorded on every call; read every tenth so the calls stay back to back
+                for name, ms in solver.timings():
+                    acc.setdefault(name, []).append(ms)
+        solver.set_option("profile", 0)
+        kern = {k: float(np.mean(v)) for k, v in acc.items()}
+
+    strong5 = None
+    if not strong and not args.no_extra_legs:            # every rank takes part (collective inside)
+        del ao, gr
+        ao = gr = None
+        torch.cuda.empty_cache()
+        strong5 = strong_leg(lib_path, dev, dist, args.backend, world, rank, "c33_b3lyp_def2svp")
+        if rank == 0 and world == 1:
+            dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)   # the same inputs again for the legs below
 
     if rank == 0:
-        dom = max(kern, key=kern.get)
-        b_alg, f_alg = kernel_model(dom, xc, ngrid, nao)
-        t_dom = kern[dom] * 1e-3
-        hbm_t, mfma_t = b_alg / (HBM_PEAK_GBS * 1e9), f_alg / (F64_MFMA_PEAK_TF * 1e12)
-        if hbm_t >= mfma_t:
-            roof = {"bound": "hbm", "achieved": b_alg / t_dom / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        t_step = dt / args.steps
+        # whole call against SURVEY 8(d): B = ngrid(8 nao c + 8) + 16 nao^2, F = 4 ngrid nao^2 + (2c + 8[c=4]) ngrid nao
+        b_all, f_all = kernel_model("xc_sweep", xc, ngrid, nao)
+        hbm_frac, mfma_frac = b_all / t_step / 1e9 / HBM_PEAK_GBS, f_all / t_step / 1e12 / F64_MFMA_PEAK_TF
+        if b_all / (HBM_PEAK_GBS * 1e9) >= f_all / (F64_MFMA_PEAK_TF * 1e12):
+            roof = {"bound": "hbm", "achieved": b_all / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}
         else:
-            roof = {"bound": "mfma", "achieved": f_alg / t_dom / 1e12, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s"}
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        tr = pmc_traffic(args.workload, dom)
-        roof["traffic"] = tr["hbm_bytes"] if tr else None
+            roof = {"bound": "mfma", "achieved": f_all / t_step / 1e12, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": mfma_frac}
+        roof.update({"scope": "whole DFT_ComputeXC call (all its kernels + the host's wait), algorithmic bytes/flops of SURVEY 8(d) / ms_per_step",
+                     "hbm_frac": hbm_frac, "mfma_frac": mfma_frac, "alg_bytes": b_all, "alg_flops": f_all,
+                     "kernel_sum_ms": float(sum(kern.values()))})
+        tr = pmc_traffic(workload, list(kern))
+        roof["traffic"] = float(sum(tr["per_kernel"].values())) if tr else None
         if tr:
             roof["traffic_source"] = "profiles/" + tr["source"]
-        roof.update({"kernel": dom, "kernel_ms": kern[dom], "alg_bytes": b_alg, "alg_flops": f_alg,
-                     "other_bound_frac": (f_alg / t_dom / 1e12 / F64_MFMA_PEAK_TF) if roof["bound"] == "hbm"
-                     else (b_alg / t_dom / 1e9 / HBM_PEAK_GBS)})
-        b_all, f_all = kernel_model("xc_sweep", xc, ngrid, nao)
+        if kern:
+            dom = max(kern, key=kern.get)
+            b_alg, f_alg = kernel_model(dom, xc, ngrid, nao)
+            t_dom = kern[dom] * 1e-3
+            roof["dominant_kernel"] = {"kernel": dom, "kernel_ms": kern[dom], "alg_bytes": b_alg, "alg_flops": f_alg,
+                                       "hbm_frac": b_alg / t_dom / 1e9 / HBM_PEAK_GBS, "mfma_frac": f_alg / t_dom / 1e12 / F64_MFMA_PEAK_TF,
+                                       "traffic": tr["per_kernel"].get(dom) if tr else None}
         line = {
-            "metric": "grid_points_per_sec", "value": world * ngrid * args.steps / dt, "unit": "grid-points/s",
+            "metric": "grid_points_per_sec", "value": total_points * args.steps / dt, "unit": "grid-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "spinup_ms": args.spinup_ms, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": t_step * 1e3, "spinup_ms": args.spinup_ms, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: DFT_ComputeXC ({xc}) nao={nao} ngrid={ngrid} per GPU, "
-                                   f"synthetic AO/grid (SURVEY 8(d) recipe), inputs resident in HBM",
+            "config": {"workload": f"{workload}: DFT_ComputeXC ({xc}) nao={nao} ngrid={ngrid_all}" + (" per GPU" if not strong else f" sharded over {world} GPU(s)") +
+                                   ", synthetic AO/grid (SURVEY 8(d) recipe), inputs resident in HBM",
                        "functional": xc, "nao": nao, "ngrid_per_gpu": ngrid,
-                       "sharding": "grid points" + ("" if world == 1 else f" x{world}, RCCL all-reduce of Vxc|Exc")},
-            "roofline": roof,
-            "sweep": {"alg_bytes": b_all, "alg_flops": f_all,
-                      "hbm_frac_of_step": b_all / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-                      "mfma_frac_of_step": f_all / (dt / args.steps) / 1e12 / F64_MFMA_PEAK_TF},
-            "kernels_ms": kern, "exc": exc,
+                       "sharding": "grid points" + ("" if world == 1 else f" x{world}, RCCL all-reduce of Vxc|Exc ({8 * (nao * nao + 1)} B)")},
+            "roofline": roof, "kernels_ms": kern, "exc": exc,
         }
-        if world == 1:
+        if strong5 is not None:
+            line["strong_config5"] = strong5
+        if world == 1 and not strong and not args.no_extra_legs:
+            line["ao_sweep"] = ao_sweep_leg(lib_path, dev)
             line["scf_iteration"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev)
+            del ao, gr
+            torch.cuda.empty_cache()
+            xa, na, ga = WORKLOADS["anthracene_b3lyp_def2tzvp"]
+            dm_a, ao_a, gr_a, w_a = synth(ga, na, True, dev, SEED)
+            line["scf_iteration_anthracene"] = scf_iteration_ms(q.DFTSolverWrapper(lib_path, xa), xa, na, ga, dm_a, ao_a, gr_a, w_a, dev, iters=7)
+            del ao_a, gr_a
+            torch.cuda.empty_cache()
+            dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)
         if world == 1 and not args.no_k_build:
-            line["k_build"] = k_build_mfma(q.build_library(), dev)
+            line["k_build"] = k_build_mfma(lib_path, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(xc, dm, ao, gr, w, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -13,7 +13,11 @@
  *   dm (nao,nao) | ao (ngrid,nao) | ao_grad (3,ngrid,nao) planar | weights (ngrid)
  *   vxc (nao,nao) overwritten | eri (nao^2,nao^2) | J, K (nao,nao) overwritten.
  * Work is enqueued on the solver's stream (default: the null stream, like the
- * reference); DFT_ComputeXC is synchronous on return (it returns Exc).
+ * reference); DFT_ComputeXC returns Exc once the call's last kernel has published
+ * it: every consumer on the solver's stream (the reference's pattern, dft.py:211)
+ * is ordered behind the call; option "strict_sync" = 1 additionally waits until
+ * the stream reports complete (consumers on other streams / mapped host reads).
+ * Every entry point runs on the device that was current at DFT_CreateSolver.
  * No function throws or aborts; failures print one line to stderr, are
  * retrievable with DFT_GetLastError(), and make DFT_ComputeXC return NaN.
  */
@@ -139,7 +143,8 @@ int DFT_EvalAO(XCSolver *solver, long long ngrid, int nao, int nshell,
  * (1 = record per-kernel HIP events for DFT_GetTimings), "ksplit" (grid chunks
  * of the generic Vxc contraction; 0 = auto), "spin_wait" (1, default: the host
  * polls the host-mapped Exc word written by the last kernel instead of sleeping
- * in hipStreamSynchronize), "ao_pt" (grid points per workgroup of DFT_EvalAO:
+ * in hipStreamSynchronize), "strict_sync" (0, default; 1 = DFT_ComputeXC also waits
+ * for the stream to report complete before returning), "ao_pt" (grid points per workgroup of DFT_EvalAO:
  * 8, 16, or 0 = auto), "rho_rows" (grid rows per workgroup of the large-basis
  * density kernel: 64, default, or 128).  Returns 0 if the key is known. */
 int DFT_SetOption(XCSolver *solver, const char *key, double value);

@@ -1,5 +1,7 @@
 """ctypes loader for the plain-C oracle (TEST INFRASTRUCTURE ONLY)."""
 import ctypes
+import fcntl
+import hashlib
 import os
 import subprocess
 
@@ -14,22 +16,50 @@ POINTWISE_KINDS = {
 }
 
 
+_SRCS = ("xc_oracle.c", "ao_oracle.c", "Makefile")
+
+
+def _src_hash():
+    h = hashlib.sha256()
+    for f in _SRCS:
+        with open(os.path.join(_HERE, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _current(path):
+    try:
+        return os.path.exists(path) and open(path + ".srchash").read().strip() == _src_hash()
+    except OSError:
+        return False
+
+
 def build(omp=False):
-    """Compile the oracle with gcc (idempotent: make decides)."""
+    """Compile the oracle with gcc.  Called by __graft_entry__.build() and tests/conftest.py only:
+    lib() below never compiles (bench.py times a prebuilt checker, it does not start a compiler)."""
     target = "_build/liboracle_omp.so" if omp else "_build/liboracle.so"
-    subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
-    return os.path.join(_HERE, target)
+    path = os.path.join(_HERE, target)
+    if _current(path):
+        return path
+    os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+    with open(path + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not _current(path):
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("LD_PRELOAD", "HSA_TOOLS_LIB") and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER"))}
+            subprocess.run(["make", "-s", "-B", "-C", _HERE, target], check=True, env=env)
+            with open(path + ".srchash", "w") as fh:
+                fh.write(_src_hash() + "\n")
+    return path
 
 
 def lib(omp=False):
     key = bool(omp)
     if key not in _LIBS:
         path = os.path.join(_HERE, "_build", "liboracle_omp.so" if omp else "liboracle.so")
-        if not os.path.exists(path) or any(
-            os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(path)
-            for s in ("xc_oracle.c", "ao_oracle.c")
-        ):
-            path = build(omp)
+        if not _current(path):
+            raise RuntimeError(f"{path} is missing or older than oracle/*.c: run `python __graft_entry__.py` "
+                               "(tests build it in conftest.py)")
         L = ctypes.CDLL(path)
         dp = ctypes.POINTER(ctypes.c_double)
         L.orc_compute_xc.restype = ctypes.c_double

@@ -45,6 +45,7 @@ struct XCSolver {
     int type = 0;
     hipStream_t stream = nullptr;
     bool device_ok = false;
+    int device = 0; // the device that was current at DFT_CreateSolver: every entry point runs there
     int num_cu = 256;
     // options
     int quirks = 1;
@@ -57,6 +58,7 @@ struct XCSolver {
     // workspace
     DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells, msym, cdy, cdc, cdv;
     int spin_wait = 1; // poll the host-mapped Exc instead of sleeping in hipStreamSynchronize
+    int strict_sync = 0; // 1: after the Exc word, also poll the stream until it reports complete (+8-10 us per call)
     double *h_exc = nullptr;   // pinned, host-mapped: the reduce kernel writes Exc here
     double *h_exc_dev = nullptr; // device alias of h_exc
     std::string last_error;
@@ -100,6 +102,22 @@ bool reserve(XCSolver *s, DevBuf &b, size_t bytes, const char *what)
     b.cap = want;
     return true;
 }
+
+// Every entry point runs on the solver's device (its workspace and stream live there): a caller that
+// switched devices since DFT_CreateSolver gets the solver's device for the call and its own back after.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const XCSolver *s)
+    {
+        if (!s || !s->device_ok) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != s->device) switched = hipSetDevice(s->device) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
 
 struct ScopedTimer {
     XCSolver *s;
@@ -268,9 +286,9 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     {
         ScopedTimer t(s, "xc_points");
         dim3 g((unsigned)nxb);
-        if (s->type == SOLVER_LDA)      hipLaunchKernelGGL(k_xc_points<0>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
-        else if (s->type == SOLVER_GGA) hipLaunchKernelGGL(k_xc_points<1>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
-        else                            hipLaunchKernelGGL(k_xc_points<2>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
+        if (s->type == SOLVER_LDA)      hipLaunchKernelGGL(k_xc_points<0>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks, (unsigned *)(exc + 1));
+        else if (s->type == SOLVER_GGA) hipLaunchKernelGGL(k_xc_points<1>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks, (unsigned *)(exc + 1));
+        else                            hipLaunchKernelGGL(k_xc_points<2>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks, (unsigned *)(exc + 1));
     }
     {
         ScopedTimer t(s, "vxc");
@@ -495,6 +513,7 @@ XCSolver *DFT_CreateSolver(int type)
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
             s->device_ok = true;
+            s->device = dev;
             s->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
         if (s->device_ok) {
@@ -516,6 +535,7 @@ void DFT_DestroySolver(XCSolver *s)
 {
     if (!s) return;
     if (s->device_ok) {
+        DeviceGuard dg(s);
         (void)hipStreamSynchronize(s->stream);
         DevBuf *bufs[] = {&s->dsym, &s->rho, &s->sigma, &s->grad, &s->coef, &s->partial,
                           &s->slabs, &s->exc, &s->jpart, &s->kpart, &s->shells, &s->msym,
@@ -536,6 +556,7 @@ double DFT_ComputeXC64(XCSolver *s, long long ngrid, int nao, unsigned long long
                        unsigned long long d_w, unsigned long long d_vxc)
 {
     if (!s) return 0.0;
+    DeviceGuard dg(s);
     const double nan = std::numeric_limits<double>::quiet_NaN();
     if (s->h_exc) *s->h_exc = nan; // before anything is enqueued: the last kernel overwrites it
     if (!xc_sweep(s, (long)ngrid, nao, (const double *)d_dm, (const double *)d_ao,
@@ -544,21 +565,35 @@ double DFT_ComputeXC64(XCSolver *s, long long ngrid, int nao, unsigned long long
     if (s->h_exc_dev) { // Exc is written into host-mapped memory by the call's last kernel
         volatile double *hx = s->h_exc;
         if (s->spin_wait) {
-            // stream order puts k_finish_exc after every Vxc store of the call;
-            // the stream query bounds the spin if a kernel faulted or Exc really is NaN
+            // The word is stored by the last block of the call's last kernel, after that kernel's Vxc stores
+            // were issued: it says "Exc is final and every kernel of the call has been dispatched and all but
+            // the tail of the last one has run".  Anything the caller does with d_vxc on the SOLVER'S stream
+            // (the reference's pattern: the null stream, d_vxc.get() at dft.py:211) is ordered behind it.
+            // A consumer on ANOTHER stream, or a host read of a mapped Vxc, needs option "strict_sync" = 1,
+            // which also polls the stream until it reports complete (the reference's blocking 8-byte copy +
+            // cudaFree, dft_solver.cu:575-582; costs 8-10 us per call, measured).  Both spins are bounded by
+            // the stream state: a faulted kernel or an Exc that really is NaN ends them.
             for (unsigned spins = 1; std::isnan(*hx); ++spins) {
                 if ((spins & 0xFFF) == 0 && hipStreamQuery(s->stream) != hipErrorNotReady) break;
                 __builtin_ia32_pause();
             }
-            if (!std::isnan(*hx)) return *hx;
+            if (s->strict_sync || std::isnan(*hx)) {
+                hipError_t q;
+                while ((q = hipStreamQuery(s->stream)) == hipErrorNotReady) __builtin_ia32_pause();
+                if (!hip_ok(s, q, "XC sweep")) return nan;
+            }
+        } else if (!hip_ok(s, hipStreamSynchronize(s->stream), "synchronise")) {
+            return nan;
         }
-        if (!hip_ok(s, hipStreamSynchronize(s->stream), "synchronise")) return nan;
-        return *hx;
+        const double out = *hx;
+        if (std::isnan(out)) set_error(s, "Exc is NaN after the sweep completed (non-finite inputs, or the finishing kernel did not run)");
+        return out;
     }
     double out = nan;
     if (!hip_ok(s, hipMemcpyAsync(&out, s->exc.p, sizeof(double), hipMemcpyDeviceToHost, s->stream), "copy Exc") ||
         !hip_ok(s, hipStreamSynchronize(s->stream), "synchronise"))
         return nan;
+    if (std::isnan(out)) set_error(s, "Exc is NaN after the sweep completed (non-finite inputs)");
     return out;
 }
 
@@ -575,6 +610,7 @@ int DFT_ComputeXCAsync(XCSolver *s, long long ngrid, int nao, unsigned long long
                        unsigned long long d_exc)
 {
     if (!s) return -1;
+    DeviceGuard dg(s);
     if (!xc_sweep(s, (long)ngrid, nao, (const double *)d_dm, (const double *)d_ao,
                   (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc, false))
         return -1;
@@ -587,6 +623,7 @@ void DFT_ComputeCoulomb(XCSolver *s, int nao, unsigned long long d_eri, unsigned
                         unsigned long long d_J)
 {
     if (!s) return;
+    DeviceGuard dg(s);
     jk(s, nao, (const double *)d_eri, (const double *)d_dm, (double *)d_J, nullptr);
 }
 
@@ -594,6 +631,7 @@ void DFT_ComputeExchange(XCSolver *s, int nao, unsigned long long d_eri, unsigne
                          unsigned long long d_K)
 {
     if (!s) return;
+    DeviceGuard dg(s);
     jk(s, nao, (const double *)d_eri, (const double *)d_dm, nullptr, (double *)d_K);
 }
 
@@ -601,6 +639,7 @@ void DFT_ComputeJK(XCSolver *s, int nao, unsigned long long d_eri, unsigned long
                    unsigned long long d_J, unsigned long long d_K)
 {
     if (!s) return;
+    DeviceGuard dg(s);
     jk(s, nao, (const double *)d_eri, (const double *)d_dm, (double *)d_J, (double *)d_K);
 }
 
@@ -609,6 +648,7 @@ int DFT_ComputeJKFactorized(XCSolver *s, int nao, int naux, int nocc, unsigned l
                             unsigned long long d_K)
 {
     if (!s) return -1;
+    DeviceGuard dg(s);
     s->n_timed = 0;
     return jk_factorized(s, nao, naux, nocc, (const double *)d_chol, (const double *)d_dm,
                          (const double *)d_cocc, (double *)d_J, (double *)d_K);
@@ -620,7 +660,9 @@ int DFT_EvalAO(XCSolver *s, long long ngrid, int nao, int nshell, const double *
                unsigned long long d_coords, unsigned long long d_ao, unsigned long long d_ao_grad)
 {
     if (!s) return -1;
+    DeviceGuard dg(s);
     s->last_error.clear();
+    s->n_timed = 0;
     if (!s->device_ok) { set_error(s, "no usable HIP device"); return -1; }
     if (ngrid <= 0 || nao <= 0 || nshell <= 0 || nprim_total <= 0) {
         set_error(s, "bad AO sizes");
@@ -697,6 +739,7 @@ int DFT_EvalAO(XCSolver *s, long long ngrid, int nao, int nshell, const double *
     // 16 points per workgroup unless their LDS tile would leave fewer than three workgroups per CU
     // (measured, Benzene: def2-SVP deriv 1 139 -> 122 us with 8; STO-3G and deriv 0 are 10 % faster with 16)
     const int ao_pt = s->ao_pt ? s->ao_pt : ((d_ao_grad ? 4 : 1) * 16 * (maxcol | 1) * 8 > 53 * 1024 ? 8 : 16);
+    ScopedTimer t(s, "eval_ao");
     launch_eval_ao(s->stream, (long)ngrid, nao, nchunk, maxcol, vec, ao_pt, s->num_cu, nshell, nprim_total, dsh, dexp, dcoef, dchunks, dorder,
                    (const double *)d_coords, (double *)d_ao, (double *)d_ao_grad);
     return hip_ok(s, hipGetLastError(), "AO launch") ? 0 : -1;
@@ -709,6 +752,7 @@ int DFT_SetOption(XCSolver *s, const char *key, double value)
     if (!strcmp(key, "path")) { s->path = (int)value; return 0; }
     if (!strcmp(key, "profile")) { s->profile = value != 0.0; return 0; }
     if (!strcmp(key, "spin_wait")) { s->spin_wait = value != 0.0; return 0; }
+    if (!strcmp(key, "strict_sync")) { s->strict_sync = value != 0.0; return 0; }
     if (!strcmp(key, "fuse_finish")) { s->fuse_finish = value != 0.0; return 0; }
     if (!strcmp(key, "rho_rows")) { s->rho_rows = value == 128.0 ? 128 : 64; return 0; }
     if (!strcmp(key, "ao_pt")) { s->ao_pt = value == 16.0 ? 16 : value == 8.0 ? 8 : 0; return 0; }
@@ -719,6 +763,7 @@ int DFT_SetOption(XCSolver *s, const char *key, double value)
 int DFT_SetStream(XCSolver *s, unsigned long long hip_stream)
 {
     if (!s) return -1;
+    DeviceGuard dg(s);
     if (s->device_ok) (void)hipStreamSynchronize(s->stream);
     s->stream = (hipStream_t)hip_stream;
     return 0;
@@ -732,6 +777,7 @@ const char *DFT_GetLastError(XCSolver *s)
 int DFT_GetTimings(XCSolver *s, double *ms, const char **names, int max_entries)
 {
     if (!s || !s->device_ok) return 0;
+    DeviceGuard dg(s);
     (void)hipStreamSynchronize(s->stream);
     int n = 0;
     for (size_t i = 0; i < s->n_timed && n < max_entries; ++i, ++n) {

@@ -18,7 +18,7 @@ for bname in ("sto-3g", "def2-svp"):
     coords = torch.as_tensor(g.coords, device=dev)
     ao = torch.empty((ngrid, sh.nao), dtype=torch.float64, device=dev); gr = torch.empty((3, ngrid, sh.nao), dtype=torch.float64, device=dev)
     for pt in (0, 16, 8):
-      s = q.DFTSolverWrapper(sys.argv[1] if len(sys.argv) > 1 else q.build_library(), 'GGA'); s.set_option('ao_pt', pt)
+      s = q.DFTSolverWrapper(sys.argv[1] if len(sys.argv) > 1 else q.library_path(), 'GGA'); s.set_option('ao_pt', pt)
       for deriv, gg in ((0, None), (1, gr)):
         t_spin = time.perf_counter() + 0.08   # GPU clock ramp: ~40 ms of sustained load before the clocks settle
         while time.perf_counter() < t_spin: s.eval_ao(sh, coords, ngrid, ao, gg)

@@ -11,7 +11,7 @@ for nao in (128, 256, 384, 512, 768, 1024):
     L = torch.randn((naux, nao, nao), dtype=torch.float64, device=dev) * 0.1
     c = torch.randn((nao, nocc), dtype=torch.float64, device=dev); dm = c @ c.T
     J = torch.zeros((nao, nao), dtype=torch.float64, device=dev); K = torch.zeros_like(J)
-    s = q.DFTSolverWrapper(q.build_library(), 'B3LYP'); s.set_option("profile", 1)
+    s = q.DFTSolverWrapper(q.library_path(), 'B3LYP'); s.set_option("profile", 1)
     out = []
     for with_j in (True, False):
         acc = {}

@@ -16,7 +16,7 @@ for name, nao, nocc, naux in cases:
     c = torch.randn((nao, nocc), dtype=torch.float64, device=dev, generator=g)
     dm = c @ c.T
     J = torch.zeros((nao, nao), dtype=torch.float64, device=dev); K = torch.zeros_like(J)
-    s = q.DFTSolverWrapper(q.build_library(), 'B3LYP')
+    s = q.DFTSolverWrapper(q.library_path(), 'B3LYP')
     s.set_option("profile", 1)
     for _ in range(2): s.compute_jk_factorized(nao, naux, nocc, L, dm, c, J, K)
     torch.cuda.synchronize()

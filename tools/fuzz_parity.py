@@ -26,7 +26,7 @@ while time.time() < t_end:
         dm, ao, gr, w = synth_inputs(ngrid, nao, seed=int(rng.integers(1 << 30)))
         if rng.random() < 0.3: w[rng.integers(0, ngrid, size=max(1, ngrid // 7))] = 0.0
         e_ref, v_ref = oracle.compute_xc(xc, dm, ao, w, gr if xc else None, quirks=bool(quirks))
-        s = q.DFTSolverWrapper(q.build_library(), names[xc]); s.set_option("path", path); s.set_option("quirks", quirks)
+        s = q.DFTSolverWrapper(q.library_path(), names[xc]); s.set_option("path", path); s.set_option("quirks", quirks)
         if rng.random() < 0.5: s.set_option("rho_rows", 128)
         d_v = torch.full((nao, nao), 3.0, dtype=torch.float64, device=dev)
         e = s.compute_xc(ngrid, nao, t(dm), t(ao), t(w), d_v, t(gr) if xc else None)
@@ -40,7 +40,7 @@ while time.time() < t_end:
         if ve > 1e-11: print(f"  note: XC {names[xc]} nao={nao} ngrid={ngrid} path={path} quirks={quirks}: dE {ee:.1e} dV {ve:.1e}", flush=True)
         if ve > 2e-9:   # look closer: the same inputs on every path, and how sensitive the oracle itself is
             for p2 in (0, 1, 2):
-                s2 = q.DFTSolverWrapper(q.build_library(), names[xc]); s2.set_option("path", p2); s2.set_option("quirks", quirks)
+                s2 = q.DFTSolverWrapper(q.library_path(), names[xc]); s2.set_option("path", p2); s2.set_option("quirks", quirks)
                 v2 = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
                 e2 = s2.compute_xc(ngrid, nao, t(dm), t(ao), t(w), v2, t(gr) if xc else None)
                 print(f"    path {p2}: dV {np.abs(v2.cpu().numpy() - v_ref).max() / np.abs(v_ref).max():.1e}", flush=True)
@@ -53,7 +53,7 @@ while time.time() < t_end:
     elif kind < 7:   # dense J/K
         n = int(rng.choice([1, 2, 5, 7, 12, 24, 36, 41])); n2 = n * n
         eri = rng.normal(size=(n2, n2)); dm = rng.normal(size=(n, n))
-        s = q.DFTSolverWrapper(q.build_library(), "B3LYP")
+        s = q.DFTSolverWrapper(q.library_path(), "B3LYP")
         d_J = torch.zeros((n, n), dtype=torch.float64, device=dev); d_K = torch.zeros_like(d_J)
         s.compute_jk(n, t(eri), t(dm), d_J, d_K); torch.cuda.synchronize()
         J_ref, K_ref = oracle.coulomb(eri, dm), oracle.exchange(eri, dm)
@@ -66,7 +66,7 @@ while time.time() < t_end:
         A = rng.normal(0, 0.3, (naux, nao, nao)); chol = 0.5 * (A + A.transpose(0, 2, 1))
         cocc = rng.normal(0, 0.7, (nao, nocc)); dm = cocc @ cocc.T
         J_ref, K_ref = oracle.jk_from_factors(chol, dm)
-        s = q.DFTSolverWrapper(q.build_library(), "B3LYP")
+        s = q.DFTSolverWrapper(q.library_path(), "B3LYP")
         d_J = torch.zeros((nao, nao), dtype=torch.float64, device=dev); d_K = torch.zeros_like(d_J)
         s.compute_jk_factorized(nao, naux, nocc, t(chol), t(dm), t(cocc), d_J, d_K); torch.cuda.synchronize()
         err = max(np.abs(d_J.cpu().numpy() - J_ref).max() / np.abs(J_ref).max(), np.abs(d_K.cpu().numpy() - K_ref).max() / np.abs(K_ref).max())
@@ -80,7 +80,7 @@ while time.time() < t_end:
         ngrid = int(rng.choice([1, 7, 8, 9, 16, 17, 100, 1000, 2049])); deriv = int(rng.integers(0, 2))
         coords = rng.uniform(-6, 6, (ngrid, 3)); coords[0] = xyz[0]
         ref = oracle.eval_ao(sh, coords, deriv=deriv)
-        s = q.DFTSolverWrapper(q.build_library(), "GGA"); s.set_option("ao_pt", int(rng.choice([0, 8, 16])))
+        s = q.DFTSolverWrapper(q.library_path(), "GGA"); s.set_option("ao_pt", int(rng.choice([0, 8, 16])))
         d_ao = torch.full((ngrid, sh.nao), 9.0, dtype=torch.float64, device=dev)
         d_gr = torch.full((3, ngrid, sh.nao), 9.0, dtype=torch.float64, device=dev) if deriv else None
         assert s.eval_ao(sh, t(coords), ngrid, d_ao, d_gr) == 0; torch.cuda.synchronize()

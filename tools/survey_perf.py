@@ -10,7 +10,7 @@ dev = torch.device('cuda:0')
 
 def time_xc(name, xc, nao, ngrid, reps=10):
     dm, ao, gr, w = synth(ngrid, nao, xc != 'LDA', dev, 1)
-    s = q.DFTSolverWrapper(q.build_library(), xc)
+    s = q.DFTSolverWrapper(q.library_path(), xc)
     v = torch.zeros(nao * nao, dtype=torch.float64, device=dev)
     for _ in range(2): s.compute_xc(ngrid, nao, dm, ao, w, v, gr)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -40,7 +40,7 @@ for n in (36, 80, 114):
     N2 = n * n
     eri = torch.randn((N2, N2), dtype=torch.float64, device=dev); dm = torch.randn((n, n), dtype=torch.float64, device=dev)
     J = torch.zeros_like(dm); K = torch.zeros_like(dm)
-    s = q.DFTSolverWrapper(q.build_library(), 'B3LYP')
+    s = q.DFTSolverWrapper(q.library_path(), 'B3LYP')
     for fn, nm in ((lambda: s.compute_coulomb(n, eri, dm, J), 'J'), (lambda: s.compute_exchange(n, eri, dm, K), 'K'), (lambda: s.compute_jk(n, eri, dm, J, K), 'J+K one pass')):
         fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): fn()
@@ -60,7 +60,7 @@ for bname in ("sto-3g", "def2-svp"):
     ngrid = 143556
     coords = torch.as_tensor(np.random.default_rng(0).normal(0, 3.0, (ngrid, 3)), device=dev)
     ao = torch.empty((ngrid, sh.nao), dtype=torch.float64, device=dev); gr = torch.empty((3, ngrid, sh.nao), dtype=torch.float64, device=dev)
-    s = q.DFTSolverWrapper(q.build_library(), 'GGA')
+    s = q.DFTSolverWrapper(q.library_path(), 'GGA')
     for deriv, g in ((0, None), (1, gr)):
         s.eval_ao(sh, coords, ngrid, ao, g); torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): s.eval_ao(sh, coords, ngrid, ao, g)
