@@ -23,6 +23,7 @@
 #include "cd_kernels.hpp"
 #include "xc_big_kernels.hpp"
 #include "xc_ws_kernels.hpp"
+#include "xc_ws16_kernels.hpp"
 #include "xc_kernels.hpp"
 
 using namespace qcdft;
@@ -55,6 +56,9 @@ struct XCSolver {
     int ao_pt = 0; // grid points per workgroup of the AO kernel: 0 auto, 8 or 16
     int fuse_finish = 1; // the Vxc reduce kernel's last block also finishes Exc (one launch fewer)
     int rho_rows = 64; // grid rows per workgroup of the large-basis rho kernel: 64 (two workgroups per CU) or 128
+    int sweep_order = 2; // bit 0: rho kernel walks the grid backwards, bit 1: Vxc kernel does (default: rho forward, Vxc backward)
+    int dbg = 0;       // diagnostics only (ablations of the sixteen-wave kernels: 1 = no plane loads, 2 = no MFMAs)
+    int ws_waves = 0;  // wave-specialised kernels (nao <= 128): 0 auto, 8 = 4+4 waves per workgroup, 16 = 8+8
     // workspace
     DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells, msym, cdy, cdc, cdv;
     int spin_wait = 1; // poll the host-mapped Exc instead of sleeping in hipStreamSynchronize
@@ -186,9 +190,13 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     }
     const int NP = ((nao + 15) / 16) * 16;
     const int nblk = (nao + 127) / 128;
-    const bool fast = s->path == 0 && nao <= 128;
-    const bool big = s->path == 0 && nao > 128;
+    // the wave-specialised kernels address a plane through ONE buffer descriptor: planes of 4 GiB or more
+    // (ngrid*nao >= 2^29) take the generic tiled kernels
+    const bool fits32 = (double)ngrid * nao * 8.0 < 4294967296.0;
+    const bool fast = s->path == 0 && nao <= 128 && fits32;
+    const bool big = s->path == 0 && nao > 128;   // nao <= 128 with planes >= 4 GiB: the generic MFMA kernels below
     const int ntv = NP / 16;
+    const bool ws16 = fast && s->ws_waves == 16; // opt-in: measured equal to the eight-wave kernels at NT = 8, slower below
     int nslab;
     long chunk = 0;
     const int nA = (nao + BG_BM - 1) / BG_BM, nB = (nao + BG_BN - 1) / BG_BN, npair = nA * nB;
@@ -228,11 +236,7 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
         !reserve(s, s->slabs, sizeof(double) * (size_t)nslab * nao * nao, "hipMalloc(slabs)") ||
         false)
         return false;
-    { // [Exc | ticket of the finishing reduce kernel]: the ticket starts at 0 and every call leaves it at 0
-        const bool fresh = s->exc.cap == 0;
-        if (!reserve(s, s->exc, 2 * sizeof(double), "hipMalloc(exc)")) return false;
-        if (fresh && !hip_ok(s, hipMemsetAsync(s->exc.p, 0, 2 * sizeof(double), s->stream), "memset(exc)")) return false;
-    }
+    if (!reserve(s, s->exc, 2 * sizeof(double), "hipMalloc(exc)")) return false; // the device-side Exc scalar
     if (gga && (!reserve(s, s->sigma, sizeof(double) * ng, "hipMalloc(sigma)") ||
                 !reserve(s, s->grad, sizeof(double) * 3 * ng, "hipMalloc(grad)")))
         return false;
@@ -253,9 +257,15 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     {
         ScopedTimer t(s, "rho");
         const int vec16 = (nao % 2 == 0) && ((((uintptr_t)ao | (uintptr_t)gx | (uintptr_t)gy | (uintptr_t)gz) & 15) == 0);
-        if (fast) {
+        if (fast && ws16) {
             dim3 g((unsigned)nslab);
-#define QCDFT_RHO(G, V) QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_rho_ws<NT, G, V>), g, dim3(WS_THREADS), 0, st, ngrid, nao, ao, gx, gy, gz, dm, rho, grad, sigma))
+#define QCDFT_RHO(G, V) QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_rho_ws16<NT, G, V>), g, dim3(W16_THREADS), 0, st, ngrid, nao, ao, gx, gy, gz, dm, rho, grad, sigma, s->dbg | ((s->sweep_order & 1) << 16)))
+            if (gga) { if (vec16) { QCDFT_RHO(true, true) } else { QCDFT_RHO(true, false) } }
+            else     { if (vec16) { QCDFT_RHO(false, true) } else { QCDFT_RHO(false, false) } }
+#undef QCDFT_RHO
+        } else if (fast) {
+            dim3 g((unsigned)nslab);
+#define QCDFT_RHO(G, V) QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_rho_ws<NT, G, V>), g, dim3(WS_THREADS), 0, st, ngrid, nao, ao, gx, gy, gz, dm, rho, grad, sigma, s->sweep_order & 1))
             if (gga) { if (vec16) { QCDFT_RHO(true, true) } else { QCDFT_RHO(true, false) } }
             else     { if (vec16) { QCDFT_RHO(false, true) } else { QCDFT_RHO(false, false) } }
 #undef QCDFT_RHO
@@ -286,16 +296,23 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     {
         ScopedTimer t(s, "xc_points");
         dim3 g((unsigned)nxb);
-        if (s->type == SOLVER_LDA)      hipLaunchKernelGGL(k_xc_points<0>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks, (unsigned *)(exc + 1));
-        else if (s->type == SOLVER_GGA) hipLaunchKernelGGL(k_xc_points<1>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks, (unsigned *)(exc + 1));
-        else                            hipLaunchKernelGGL(k_xc_points<2>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks, (unsigned *)(exc + 1));
+        if (s->type == SOLVER_LDA)      hipLaunchKernelGGL(k_xc_points<0>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
+        else if (s->type == SOLVER_GGA) hipLaunchKernelGGL(k_xc_points<1>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
+        else                            hipLaunchKernelGGL(k_xc_points<2>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
     }
     {
         ScopedTimer t(s, "vxc");
         const int vec16 = (nao % 2 == 0) && ((((uintptr_t)ao | (uintptr_t)gx | (uintptr_t)gy | (uintptr_t)gz) & 15) == 0);
-        if (fast) {
+        if (fast && ws16) {
             dim3 g((unsigned)nslab);
-#define QCDFT_VXC(G, V, S) QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_vxc_ws<NT, G, V, S>), g, dim3(WS_THREADS), 0, st, ngrid, nao, ao, gx, gy, gz, coef, slabs))
+#define QCDFT_VXC(G, V, S) QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_vxc_ws16<NT, G, V, S>), g, dim3(W16_THREADS), 0, st, ngrid, nao, ao, gx, gy, gz, coef, slabs, s->dbg | ((s->sweep_order & 2) << 15)))
+            if (s->type == SOLVER_B3LYP) { if (vec16) { QCDFT_VXC(true, true, true) } else { QCDFT_VXC(true, false, true) } }
+            else if (gga) { if (vec16) { QCDFT_VXC(true, true, false) } else { QCDFT_VXC(true, false, false) } }
+            else          { if (vec16) { QCDFT_VXC(false, true, false) } else { QCDFT_VXC(false, false, false) } }
+#undef QCDFT_VXC
+        } else if (fast) {
+            dim3 g((unsigned)nslab);
+#define QCDFT_VXC(G, V, S) QCDFT_NT_SWITCH(ntv, hipLaunchKernelGGL((k_vxc_ws<NT, G, V, S>), g, dim3(WS_THREADS), 0, st, ngrid, nao, ao, gx, gy, gz, coef, slabs, (s->sweep_order >> 1) & 1))
             if (s->type == SOLVER_B3LYP) { if (vec16) { QCDFT_VXC(true, true, true) } else { QCDFT_VXC(true, false, true) } }
             else if (gga) { if (vec16) { QCDFT_VXC(true, true, false) } else { QCDFT_VXC(true, false, false) } }
             else          { if (vec16) { QCDFT_VXC(false, true, false) } else { QCDFT_VXC(false, false, false) } }
@@ -331,7 +348,7 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
         } else if (s->fuse_finish) { // wave-specialised slabs are already symmetrised for B3LYP
             // last launch of the call: its last-ticket block also finishes Exc (device scalar + host-mapped word)
             hipLaunchKernelGGL((k_reduce_slabs8<false, true>), g, dim3(256), 0, st, nao, nslab, slabs, vxc, nxb, partial, exc,
-                               want_host_exc ? s->h_exc_dev : nullptr, (unsigned *)(exc + 1));
+                               want_host_exc ? s->h_exc_dev : nullptr);
             return hip_ok(s, hipGetLastError(), "XC sweep launch");
         } else {
             hipLaunchKernelGGL(k_reduce_slabs8<false>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
@@ -754,6 +771,9 @@ int DFT_SetOption(XCSolver *s, const char *key, double value)
     if (!strcmp(key, "spin_wait")) { s->spin_wait = value != 0.0; return 0; }
     if (!strcmp(key, "strict_sync")) { s->strict_sync = value != 0.0; return 0; }
     if (!strcmp(key, "fuse_finish")) { s->fuse_finish = value != 0.0; return 0; }
+    if (!strcmp(key, "sweep_order")) { s->sweep_order = (int)value & 3; return 0; }
+    if (!strcmp(key, "dbg")) { s->dbg = (int)value; return 0; }
+    if (!strcmp(key, "ws_waves")) { s->ws_waves = value == 16.0 ? 16 : value == 8.0 ? 8 : 0; return 0; }
     if (!strcmp(key, "rho_rows")) { s->rho_rows = value == 128.0 ? 128 : 64; return 0; }
     if (!strcmp(key, "ao_pt")) { s->ao_pt = value == 16.0 ? 16 : value == 8.0 ? 8 : 0; return 0; }
     if (!strcmp(key, "ksplit")) { s->ksplit = value > 0 ? (int)value : 0; return 0; }

@@ -102,8 +102,15 @@ __global__ __launch_bounds__(256) void k_sum_slabs8(size_t nelem, int nslab, siz
     const size_t e = (size_t)blockIdx.x * 32 + el;
     double s = 0.0;
     if (e < nelem) {
-#pragma unroll 4
-        for (int k = grp; k < nslab; k += 8) s += part[(size_t)k * stride + e];
+        int k = grp; // 16 loads in flight per thread, summed in slab order (see k_reduce_slabs8)
+        for (; k + 8 * 15 < nslab; k += 8 * 16) {
+            double v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = part[(size_t)(k + 8 * q) * stride + e];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += v[q];
+        }
+        for (; k < nslab; k += 8) s += part[(size_t)k * stride + e];
     }
     red[threadIdx.x] = s;
     __syncthreads();

@@ -212,14 +212,9 @@ __global__ __launch_bounds__(256) void k_xc_points(long ngrid, const double *__r
                                                    const double *__restrict__ grad,
                                                    const double *__restrict__ w,
                                                    double *__restrict__ coef,
-                                                   double *__restrict__ partial, int quirks,
-                                                   unsigned *__restrict__ ticket)
+                                                   double *__restrict__ partial, int quirks)
 {
     __shared__ double red[4];
-    // The finishing reduce kernel of this call counts its blocks on `ticket`.  It is zeroed HERE, by an
-    // earlier kernel of the same call (stream order makes it visible), so a faulted or partial earlier
-    // call that left a count behind cannot keep this call from publishing Exc.
-    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
     double e = 0.0;
     if (g < ngrid) {

@@ -50,20 +50,29 @@ template <int NT> struct WsCfg {
     static constexpr int LDX = ((NCOL + 31) / 32) * 32 + 16;  // = 16 (mod 32)
 };
 
-// Plane tiles are read with BUFFER loads: a wave-uniform descriptor (SGPRs) whose base is the
-// tile's first row and whose range ends at the END OF THE PLANE, plus one 32-bit per-thread byte
-// offset and immediate column offsets.  The hardware range check returns zeros for rows past
-// the grid, so the loader stream carries no masks, clamps or 64-bit VALU address arithmetic --
-// it has to fit in the ~2.5 VALU issue slots per fp64 MFMA that a wave gets next to a
-// saturating MFMA wave on the same SIMD (measured, tools/coissue_probe.hip).
+// Plane tiles are read with BUFFER loads: a wave-uniform descriptor (SGPRs), a wave-uniform byte
+// offset of the tile (one SGPR), one 32-bit per-thread byte offset and immediate column offsets.
+// The hardware range check returns zeros for rows past the grid, so the loader stream carries no
+// masks, clamps or 64-bit address arithmetic -- it has to fit in the few issue slots a wave gets
+// next to a saturating MFMA wave on the same SIMD (measured, tools/coissue_probe*.hip).
 // Columns >= nao of a staged row hold finite data of the next row; they only ever multiply
 // exact zeros (zero-padded Ds rows / discarded V tiles).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// `live` = false gives a ZERO-record descriptor: every load through it is dropped by the range
-// check (returns 0, no memory traffic) yet still counts in vmcnt -- used for the pipeline-drain
-// steps, so the loader loop stays branch-free without re-reading a tile.
+// ONE descriptor per plane for the whole kernel (base = plane start, range = the plane); the sub-tile is
+// selected by the SGPR offset of the load, which the hardware adds to the address AND to the range check
+// (tools/bufrange_probe.hip: lanes with voffset + soffset >= num_records read 0 on gfx950).  A drain step
+// passes soffset = num_records: every lane is out of range, no memory traffic, the load still counts in
+// vmcnt, so the loader loop stays branch-free.  This replaced a per-step, per-plane descriptor rebuild
+// (~110 scalar instructions per sub-tile): next to a saturating fp64-MFMA wave a wave issues ONE scalar
+// instruction per 16 cycles and one vector instruction per ~24 (tools/coissue_probe3.hip,
+// profiles/r02_coissue_probe3.txt), so those scalar instructions alone cost ~1800 of the 4096 cycles the
+// matrix pipe needs per sub-tile and the loaders -- not HBM, not the MFMAs -- set the pace.
+// Planes of 4 GiB or more do not fit a descriptor range: the host routes them to the generic kernels.
+// Per-tile descriptor (base = the tile's first element, range = to the end of the plane; `live` = false
+// gives zero records): the form the large-basis and Cholesky kernels use, whose planes may exceed 4 GiB and
+// whose MFMA loops are long enough to hide the rebuild.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_tile_rsrc(const double *plane, long plane_elems,
                                                                   long first_elem, bool live = true)
 {
@@ -71,33 +80,47 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_tile_rsrc(const double *
     const unsigned nrec = !live ? 0u : remain > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)remain;
     return __builtin_amdgcn_make_buffer_rsrc((void *)(plane + first_elem), 0, nrec, 0x00020000);
 }
-// pair (c, c+1) of one row: `voff` = byte offset of (row, 2*seg) in the tile, IMM = 256*j
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const double *plane, long plane_elems)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)plane, 0, (unsigned)(plane_elems * 8), 0x00020000);
+}
+// pair (c, c+1) of one row: `voff` = byte offset of (row, 2*seg) in the tile, IMM = byte offset of the
+// column group, `soff` = byte offset of the tile in the plane
 template <bool VEC, int IMM>
-__device__ __forceinline__ void buf_load_pair(__amdgpu_buffer_rsrc_t r, unsigned voff, double &a, double &b)
+__device__ __forceinline__ void buf_load_pair(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double &a, double &b)
 {
     if (VEC) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM, 0, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM, soff, 0);
         a = __hiloint2double((int)v[1], (int)v[0]);
         b = __hiloint2double((int)v[3], (int)v[2]);
     } else { // odd nao or 8-byte aligned base: two 8-byte loads
-        const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM, 0, 0);
-        const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM + 8, 0, 0);
+        const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM, soff, 0);
+        const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM + 8, soff, 0);
         a = __hiloint2double((int)lo[1], (int)lo[0]);
         b = __hiloint2double((int)hi[1], (int)hi[0]);
     }
 }
-template <int JN, bool VEC, int J = 0>
-__device__ __forceinline__ void buf_load_row(__amdgpu_buffer_rsrc_t r, unsigned voff, double (&dst)[2 * JN])
+// JN column groups of GW bytes each (GW = 256: 16 lanes per grid row, 512: 32 lanes per row)
+template <int JN, bool VEC, int GW = 256, int J = 0>
+__device__ __forceinline__ void buf_load_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double (&dst)[2 * JN])
 {
     if constexpr (J < JN) {
-        buf_load_pair<VEC, 256 * J>(r, voff, dst[2 * J], dst[2 * J + 1]);
-        buf_load_row<JN, VEC, J + 1>(r, voff, dst);
+        buf_load_pair<VEC, GW * J>(r, voff, soff, dst[2 * J], dst[2 * J + 1]);
+        buf_load_row<JN, VEC, GW, J + 1>(r, voff, soff, dst);
     }
 }
-__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned voff)
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return __hiloint2double((int)v[1], (int)v[0]);
+}
+// Sub-tile of workgroup `b` at its s-th step; `rev` walks the grid from its END (the Vxc kernel does:
+// it starts where the density kernel stopped, so the tail of the planes is still in the Infinity Cache:
+// -5 % on either kernel, tools/ws_order.py).
+__device__ __forceinline__ unsigned ws_tile(unsigned ntile, unsigned b, unsigned s, unsigned nwg, int rev)
+{
+    const unsigned t = b + s * nwg;
+    return rev ? ntile - 1u - t : t;
 }
 
 // Sum over the 16 lanes of a DPP row with row rotations: pure VALU, no LDS traffic (the
@@ -129,7 +152,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_vxc_ws(long ngrid, int nao,
                                                           const double *__restrict__ gy,
                                                           const double *__restrict__ gz,
                                                           const double *__restrict__ coef,
-                                                          double *__restrict__ slabs)
+                                                          double *__restrict__ slabs, int rev)
 {
     using C = WsCfg<NT>;
     constexpr int TILE = WS_ROWS * C::LDX;
@@ -250,31 +273,39 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_vxc_ws(long ngrid, int nao,
         double p0[2][2 * C::JN], p1[2][2 * C::JN], p2[2][2 * C::JN], p3[2][2 * C::JN];
         double k0[2], k1[2], k2[2], k3[2];
 
-        // Loads are issued UNCONDITIONALLY (sub-tile index clamped to the workgroup's last one):
-        // with a conditional issue the number of outstanding loads is path-dependent and the
+        // Loads are issued UNCONDITIONALLY (a drain step's tile offset is the plane size: out of range,
+        // no traffic): with a conditional issue the number of outstanding loads is path-dependent and the
         // compiler falls back to `s_waitcnt vmcnt(0)`, which drains the younger register set as
         // well and collapses the prefetch to one step (measured: 7k cycles per step).
         const long plane = ngrid * (long)nao;
         const unsigned voff = (unsigned)(row * nao + 2 * seg) * 8u, koff = (unsigned)row * 8u;
-        auto issue = [&](int set, long s) {
-            const bool live = s < nloc;                                               // drain steps load nothing
-            const long row0 = (blockIdx.x + min(s, nloc - 1) * gridDim.x) * WS_ROWS; // wave-uniform
-            const long e0 = row0 * nao;
-            k0[set] = buf_load_f64(plane_tile_rsrc(c0, ngrid, row0, live), koff);
+        const unsigned tile_b = (unsigned)(WS_ROWS * nao) * 8u, ktile_b = WS_ROWS * 8u;
+        const unsigned plane_b = (unsigned)(plane * 8), coef_b = (unsigned)(ngrid * 8);
+        const __amdgpu_buffer_rsrc_t r0 = plane_rsrc(ao, plane), r1 = plane_rsrc(GRAD ? gx : ao, plane),
+                                     r2 = plane_rsrc(GRAD ? gy : ao, plane), r3 = plane_rsrc(GRAD ? gz : ao, plane),
+                                     q0 = plane_rsrc(c0, ngrid), q1 = plane_rsrc(GRAD ? c1 : c0, ngrid),
+                                     q2 = plane_rsrc(GRAD ? c2 : c0, ngrid), q3 = plane_rsrc(GRAD ? c3 : c0, ngrid);
+        auto issue = [&](int set, unsigned s) {
+            const bool live = s < (unsigned)nloc;                         // drain steps load nothing
+            const unsigned t = ws_tile((unsigned)ntile, blockIdx.x, s, gridDim.x, rev); // wave-uniform
+            const unsigned so = live ? t * tile_b : plane_b, ko = live ? t * ktile_b : coef_b;
+            k0[set] = buf_load_f64(q0, koff, ko);
             if (GRAD) {
-                k1[set] = buf_load_f64(plane_tile_rsrc(c1, ngrid, row0, live), koff);
-                k2[set] = buf_load_f64(plane_tile_rsrc(c2, ngrid, row0, live), koff);
-                k3[set] = buf_load_f64(plane_tile_rsrc(c3, ngrid, row0, live), koff);
+                k1[set] = buf_load_f64(q1, koff, ko);
+                k2[set] = buf_load_f64(q2, koff, ko);
+                k3[set] = buf_load_f64(q3, koff, ko);
             }
-            buf_load_row<C::JN, VEC>(plane_tile_rsrc(ao, plane, e0, live), voff, p0[set]);
+            buf_load_row<C::JN, VEC>(r0, voff, so, p0[set]);
             if (GRAD) {
-                buf_load_row<C::JN, VEC>(plane_tile_rsrc(gx, plane, e0, live), voff, p1[set]);
-                buf_load_row<C::JN, VEC>(plane_tile_rsrc(gy, plane, e0, live), voff, p2[set]);
-                buf_load_row<C::JN, VEC>(plane_tile_rsrc(gz, plane, e0, live), voff, p3[set]);
+                buf_load_row<C::JN, VEC>(r1, voff, so, p1[set]);
+                buf_load_row<C::JN, VEC>(r2, voff, so, p2[set]);
+                buf_load_row<C::JN, VEC>(r3, voff, so, p3[set]);
             }
         };
         issue(0, 0);
+        __builtin_amdgcn_sched_barrier(0); // program order: set 0 must be the OLDER one when the loop waits for it
         issue(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
 #ifdef QCDFT_STAMPS
         unsigned long long st_acc[4] = {0, 0, 0, 0};
 #endif
@@ -307,7 +338,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_vxc_ws(long ngrid, int nao,
                         }
                     }
                     QCDFT_T(tm);
-                    issue(set, step + 2);
+                    issue(set, (unsigned)step + 2u);
                     QCDFT_ACC(3, tw, tm);
                 }
                 QCDFT_T(tb);
@@ -346,7 +377,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
                                                           const double *__restrict__ dm,
                                                           double *__restrict__ rho,
                                                           double *__restrict__ grad,
-                                                          double *__restrict__ sigma)
+                                                          double *__restrict__ sigma, int rev)
 {
     using C = WsCfg<NT>;
     constexpr int NKS = 4 * NT;       // k-steps over the padded AO index
@@ -420,23 +451,37 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
         double ph[2][2 * C::JN];                                           // AO of sub-tiles s, s+1
         double pgx[2][2 * C::JN], pgy[2][2 * C::JN], pgz[2][2 * C::JN];   // gradients of s-2.., see below
 
-        auto row_of = [&](long s) { return (blockIdx.x + s * gridDim.x) * WS_ROWS + row; };
-        // unconditional issue with a clamped sub-tile index: see k_vxc_ws
+        auto row_of = [&](long s) { return (long)ws_tile((unsigned)ntile, blockIdx.x, (unsigned)s, gridDim.x, rev) * WS_ROWS + row; };
+        // unconditional issue, drain steps out of range: see k_vxc_ws
         const long plane = ngrid * (long)nao;
         const unsigned voff = (unsigned)(row * nao + 2 * seg) * 8u;
-        auto issue_ao = [&](int set, long s) {
-            const long row0 = (blockIdx.x + min(s, nloc - 1) * gridDim.x) * WS_ROWS; // wave-uniform
-            buf_load_row<C::JN, VEC>(plane_tile_rsrc(ao, plane, row0 * nao, s < nloc), voff, ph[set]);
+        const unsigned tile_b = (unsigned)(WS_ROWS * nao) * 8u, plane_b = (unsigned)(plane * 8);
+        const __amdgpu_buffer_rsrc_t r0 = plane_rsrc(ao, plane), r1 = plane_rsrc(GRAD ? gx : ao, plane),
+                                     r2 = plane_rsrc(GRAD ? gy : ao, plane), r3 = plane_rsrc(GRAD ? gz : ao, plane);
+        auto tile_off = [&](unsigned s) {
+            return s < (unsigned)nloc ? ws_tile((unsigned)ntile, blockIdx.x, s, gridDim.x, rev) * tile_b : plane_b;
         };
-        auto issue_grad = [&](int set, long s) {
-            const long e0 = (blockIdx.x + min(s, nloc - 1) * gridDim.x) * WS_ROWS * (long)nao;
-            const bool live = s < nloc;
-            buf_load_row<C::JN, VEC>(plane_tile_rsrc(gx, plane, e0, live), voff, pgx[set]);
-            buf_load_row<C::JN, VEC>(plane_tile_rsrc(gy, plane, e0, live), voff, pgy[set]);
-            buf_load_row<C::JN, VEC>(plane_tile_rsrc(gz, plane, e0, live), voff, pgz[set]);
+        auto issue_ao = [&](int set, unsigned s) { buf_load_row<C::JN, VEC>(r0, voff, tile_off(s), ph[set]); };
+        auto issue_grad = [&](int set, unsigned s) {
+            const unsigned so = tile_off(s);
+            buf_load_row<C::JN, VEC>(r1, voff, so, pgx[set]);
+            buf_load_row<C::JN, VEC>(r2, voff, so, pgy[set]);
+            buf_load_row<C::JN, VEC>(r3, voff, so, pgz[set]);
         };
+        // Prologue in the loop's own issue order (AO 0, gradients 0, AO 1, gradients 1; the gradient loads are
+        // drain-type: out of range, no traffic, into registers the loop overwrites before it reads them),
+        // pinned with scheduling barriers.  The wait the compiler puts at the loop header is the MINIMUM over
+        // the entry path and the back edge of "loads younger than the set consumed first": a prologue that
+        // issues fewer or reordered loads turned that wait into vmcnt(0) -- a drain of the whole prefetch
+        // once per trip (round-1 ISA).
         issue_ao(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (GRAD) issue_grad(0, (unsigned)nloc);
+        __builtin_amdgcn_sched_barrier(0);
         issue_ao(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (GRAD) issue_grad(1, (unsigned)nloc);
+        __builtin_amdgcn_sched_barrier(0);
 
         for (long base = 0; base < nstep; base += WS_RING) {
 #pragma unroll
@@ -452,13 +497,14 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
                         if (c < C::NCOL)
                             *reinterpret_cast<double2 *>(&A[row * C::LDA + c]) = make_double2(ph[set][2 * j], ph[set][2 * j + 1]);
                     }
-                    issue_ao(set, step + 2);
+                    issue_ao(set, (unsigned)step + 2u);
                 }
                 // (b) row dots of sub-tile step-2: X from the X ring, AO from ring slot (u+2)%4,
                 //     gradients from register set `set` (loaded at step-2)
                 { // for step < 2 this runs on never-written LDS; nothing is stored (row_ok false)
-                    const long g = row_of(step - 2);
-                    const bool row_ok = step >= 2 && step - 2 < nloc && g < ngrid;
+                    const bool in_range = step >= 2 && step - 2 < nloc;
+                    const long g = row_of(in_range ? step - 2 : 0);
+                    const bool row_ok = in_range && g < ngrid;
                     const double *A = As + ((u + 2) % WS_RING) * ATILE;
                     const double *X = Xs + (u & 1) * XTILE;
                     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -495,7 +541,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
                     }
                 }
                 // (c) gradients of sub-tile `step` into the set just freed (consumed at step+2)
-                if (GRAD) issue_grad(set, step);
+                if (GRAD) issue_grad(set, (unsigned)step);
                 __syncthreads();
             }
         }
@@ -506,7 +552,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
 // of k_xc_points (reduce_sum_kernel, src/dft_solver.cu:285-292, made deterministic), stored to the
 // device scalar and, if given, to host-mapped memory.  Stream order puts it after every Vxc store
 // of the call, so the host may return as soon as it sees the value (no copy launch, no sleeping
-// synchronise).  (A last-block ticket inside the reduce kernel was tried first: its per-block
+// synchronise).  (A last-block ticket with a fence inside the reduce kernel was tried first: its per-block
 // __threadfence() cost 10-30 us.)
 __global__ __launch_bounds__(256) void k_finish_exc(long npart, const double *__restrict__ partial,
                                                     double *__restrict__ exc_dev, double *exc_host)
@@ -533,19 +579,14 @@ __global__ __launch_bounds__(256) void k_finish_exc(long npart, const double *__
 // slab groups per block, then a fixed tree over the groups.  SYM adds the transpose with
 // transposed reads (validation path only; the production paths symmetrise in-kernel or with
 // k_symmetrize).
-// FIN: the block that draws the last ticket also does k_finish_exc's job (fixed-order sum of the Exc
-// partials -> device scalar and host-mapped word), saving that launch and its dispatch gap (~7 us of a
-// 286 us call).  No fence goes with the ticket: the partials come from an earlier kernel, and everything a
-// caller does with V afterwards is ordered behind this kernel by the stream -- the host-mapped word only
-// says "Exc is final", which is all DFT_ComputeXC returns.  (The per-block device-scope __threadfence() of a
-// first attempt cost 10-30 us: every block's L2 write-back request queues at the L2.)
+// FIN: the highest-index block also does k_finish_exc's job (see the comment at the end of the kernel), saving
+// that launch and its dispatch gap.
 template <bool SYM, bool FIN = false>
 __global__ __launch_bounds__(256) void k_reduce_slabs8(int nao, int nslab,
                                                        const double *__restrict__ slabs,
                                                        double *__restrict__ V,
                                                        long npart = 0, const double *__restrict__ partial = nullptr,
-                                                       double *__restrict__ exc_dev = nullptr, double *exc_host = nullptr,
-                                                       unsigned *ticket = nullptr)
+                                                       double *__restrict__ exc_dev = nullptr, double *exc_host = nullptr)
 {
     __shared__ double part[256];
     const size_t n2 = (size_t)nao * nao;
@@ -555,10 +596,23 @@ __global__ __launch_bounds__(256) void k_reduce_slabs8(int nao, int nslab,
     if (e < n2) {
         const int a = (int)(e / nao), b = (int)(e - (size_t)a * nao);
         const size_t et = (size_t)b * nao + a;
-#pragma unroll 4
-        for (int k = grp; k < nslab; k += 8) {
-            double v = slabs[k * n2 + e];
-            if (SYM) v += slabs[k * n2 + et]; // (x + y) == (y + x): V comes out bitwise symmetric
+        // 16 slab loads in flight per thread (the slabs were written a moment ago and sit in L2 / the
+        // Infinity Cache: the sum is latency-bound, 4 in flight took 15.6 us for 26.6 MB), summed in slab
+        // order whatever the unrolling: bitwise reproducible
+        int k = grp;
+        for (; k + 8 * 15 < nslab; k += 8 * 16) {
+            double v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                v[q] = slabs[(size_t)(k + 8 * q) * n2 + e];
+                if (SYM) v[q] += slabs[(size_t)(k + 8 * q) * n2 + et]; // (x + y) == (y + x): V comes out bitwise symmetric
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += v[q];
+        }
+        for (; k < nslab; k += 8) {
+            double v = slabs[(size_t)k * n2 + e];
+            if (SYM) v += slabs[(size_t)k * n2 + et];
             s += v;
         }
     }
@@ -569,11 +623,14 @@ __global__ __launch_bounds__(256) void k_reduce_slabs8(int nao, int nslab,
         V[e] = ((p[0] + p[32]) + (p[64] + p[96])) + ((p[128] + p[160]) + (p[192] + p[224]));
     }
     if (FIN) {
-        __shared__ int last;
-        __syncthreads();
-        if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-        __syncthreads();
-        if (last) {
+        // The block with the HIGHEST index (dispatched last) also sums the Exc partials of k_xc_points -- an
+        // earlier kernel of the call, complete by stream order -- into the device scalar and the host-mapped
+        // word.  No ticket: 406 blocks drawing tickets on one address serialise at ~12 ns each, which cost
+        // more (15.0 us) than a separate finishing launch (12.7 us); this form costs neither.  The word
+        // therefore says "Exc is final and the call's last kernel is finishing" -- consumers on the solver's
+        // stream are ordered behind it, others use option strict_sync (include/dft_solver.h).
+        if (blockIdx.x == gridDim.x - 1) {
+            __syncthreads();
             double x = 0.0;
             for (long i = threadIdx.x; i < npart; i += 256) x += partial[i];
             part[threadIdx.x] = x;
@@ -583,7 +640,6 @@ __global__ __launch_bounds__(256) void k_reduce_slabs8(int nao, int nslab,
                 __syncthreads();
             }
             if (threadIdx.x == 0) {
-                *ticket = 0; // ready for the next call on this solver
                 exc_dev[0] = part[0];
                 if (exc_host) {
                     *(volatile double *)exc_host = part[0];
