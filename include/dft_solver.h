@@ -103,6 +103,19 @@ void DFT_ComputeJK(XCSolver *solver, int nao,
                    unsigned long long d_J_ptr,
                    unsigned long long d_K_ptr);
 
+/* The same contractions restricted to ERI rows (i, j) with i_lo <= i < i_hi: d_eri_rows points at row
+ * (i_lo, 0) of the (nao^2, nao^2) matrix, i.e. at a rank's resident ROW BLOCK when the dense ERI is
+ * sharded over GPUs (the reference is single-GPU, dft_solver.cu:550-555 / dft.py:218 are the
+ * whole-matrix forms).  J receives this block's partial sum over rows for EVERY column (the reference's
+ * OP_N dgemv is a sum over rows), K receives rows [i_lo, i_hi) and zeros elsewhere: summing the outputs of
+ * all blocks (one all-reduce) gives the whole-matrix J and K.  Either output may be 0.  Asynchronous;
+ * returns 0 or -1 (DFT_GetLastError). */
+int DFT_ComputeJKRows(XCSolver *solver, int nao, int i_lo, int i_hi,
+                      unsigned long long d_eri_rows,
+                      unsigned long long d_dm,
+                      unsigned long long d_J,
+                      unsigned long long d_K);
+
 /* J and K from a factorised ERI, (ij|kl) ~= sum_P L[P][i][j] L[P][k][l] (pivoted
  * Cholesky vectors, d_chol_ptr: (naux, nao, nao) f64 C-order, every L[P] symmetric).
  * Same matrices as DFT_ComputeCoulomb (dft_solver.cu:550-555, dft.py:203) and the

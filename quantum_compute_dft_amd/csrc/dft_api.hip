@@ -359,38 +359,46 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     return hip_ok(s, hipGetLastError(), "XC sweep launch");
 }
 
-void jk(XCSolver *s, int nao, const double *eri, const double *dm, double *J, double *K)
+// J and/or K from rows (i, j), i in [i0, i0 + ni), of the dense ERI; `eri` points at row (i0, 0).
+// i0 = 0, ni = nao is the reference's whole-matrix contraction; a proper sub-range is one rank's share of
+// the row sharding: partial J over all columns, rows [i0, i0 + ni) of K, zeros elsewhere.
+void jk(XCSolver *s, int nao, const double *eri, const double *dm, double *J, double *K, int i0 = 0, int ni = -1)
 {
     s->last_error.clear();
     if (!s->device_ok) { set_error(s, "no usable HIP device"); return; }
     if (nao <= 0 || nao > JK_COLS) { set_error(s, "dense-ERI J/K needs 1 <= nao <= %d (got %d)", JK_COLS, nao); return; }
+    if (ni < 0) ni = nao;
+    if (i0 < 0 || ni <= 0 || i0 + ni > nao) { set_error(s, "dense-ERI J/K: bad row range [%d, %d) of %d", i0, i0 + ni, nao); return; }
     if (!J && !K) return;
     const int n = nao;
     const size_t N2 = (size_t)n * n;
     const int KB = std::max(1, std::min(n, JK_COLS / n));
     const int ncb = (n + KB - 1) / KB;
-    // enough workgroups to fill the chip: split the j range when n*ncb is small
+    // enough workgroups to fill the chip: split the j range when ni*ncb is small
     int jsplit = 1;
-    while ((long)n * ncb * jsplit < 4L * s->num_cu && jsplit * 2 <= n) jsplit *= 2;
-    const int nslabJ = n * jsplit;
+    while ((long)ni * ncb * jsplit < 4L * s->num_cu && jsplit * 2 <= n) jsplit *= 2;
+    const int nslabJ = ni * jsplit;
     if (J && !reserve(s, s->jpart, sizeof(double) * nslabJ * N2, "hipMalloc(Jpart)")) return;
-    if (K && !reserve(s, s->kpart, sizeof(double) * jsplit * N2, "hipMalloc(Kpart)")) return;
+    if (K && !reserve(s, s->kpart, sizeof(double) * jsplit * (size_t)ni * n, "hipMalloc(Kpart)")) return;
     double *jp = (double *)s->jpart.p, *kp = (double *)s->kpart.p;
-    dim3 g(ncb, n * jsplit);
+    dim3 g(ncb, ni * jsplit);
     hipStream_t st = s->stream;
     const bool vec = (n % 2 == 0) && (((uintptr_t)eri & 15) == 0);
 #define QCDFT_JK(WJ, WK)                                                                                                  \
     do {                                                                                                                  \
-        if (vec) hipLaunchKernelGGL((k_jk_stream<WJ, WK, true>), g, dim3(256), 0, st, n, KB, jsplit, eri, dm, jp, kp);    \
-        else     hipLaunchKernelGGL((k_jk_stream<WJ, WK, false>), g, dim3(256), 0, st, n, KB, jsplit, eri, dm, jp, kp);   \
+        if (vec) hipLaunchKernelGGL((k_jk_stream<WJ, WK, true>), g, dim3(256), 0, st, n, KB, jsplit, i0, ni, eri, dm, jp, kp);    \
+        else     hipLaunchKernelGGL((k_jk_stream<WJ, WK, false>), g, dim3(256), 0, st, n, KB, jsplit, i0, ni, eri, dm, jp, kp);   \
     } while (0)
     if (J && K) QCDFT_JK(true, true);
     else if (J) QCDFT_JK(true, false);
     else        QCDFT_JK(false, true);
 #undef QCDFT_JK
-    dim3 gr((unsigned)((N2 + 31) / 32));
-    if (J) hipLaunchKernelGGL(k_sum_slabs8, gr, dim3(256), 0, st, N2, nslabJ, N2, jp, J);
-    if (K) hipLaunchKernelGGL(k_sum_slabs8, gr, dim3(256), 0, st, N2, jsplit, N2, kp, K);
+    if (J) hipLaunchKernelGGL(k_sum_slabs8, dim3((unsigned)((N2 + 31) / 32)), dim3(256), 0, st, N2, nslabJ, N2, jp, J);
+    if (K) {
+        const size_t nk = (size_t)ni * n;
+        if (ni != n) (void)hipMemsetAsync(K, 0, sizeof(double) * N2, st);
+        hipLaunchKernelGGL(k_sum_slabs8, dim3((unsigned)((nk + 31) / 32)), dim3(256), 0, st, nk, jsplit, nk, kp, K + (size_t)i0 * n);
+    }
     hip_ok(s, hipGetLastError(), "J/K launch");
 }
 
@@ -516,7 +524,7 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
 
 extern "C" {
 
-int DFT_GetVersion(void) { return 1; }
+int DFT_GetVersion(void) { return 2; }
 
 XCSolver *DFT_CreateSolver(int type)
 {
@@ -658,6 +666,15 @@ void DFT_ComputeJK(XCSolver *s, int nao, unsigned long long d_eri, unsigned long
     if (!s) return;
     DeviceGuard dg(s);
     jk(s, nao, (const double *)d_eri, (const double *)d_dm, (double *)d_J, (double *)d_K);
+}
+
+int DFT_ComputeJKRows(XCSolver *s, int nao, int i_lo, int i_hi, unsigned long long d_eri_rows,
+                      unsigned long long d_dm, unsigned long long d_J, unsigned long long d_K)
+{
+    if (!s) return -1;
+    DeviceGuard dg(s);
+    jk(s, nao, (const double *)d_eri_rows, (const double *)d_dm, (double *)d_J, (double *)d_K, i_lo, i_hi - i_lo);
+    return s->last_error.empty() ? 0 : -1;
 }
 
 int DFT_ComputeJKFactorized(XCSolver *s, int nao, int naux, int nocc, unsigned long long d_chol,

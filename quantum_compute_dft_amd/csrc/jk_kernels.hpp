@@ -24,7 +24,7 @@ constexpr int JK_COLS = 1024; // columns per workgroup (4 per thread)
 // VEC (n even: every ERI row is 16-byte aligned): each thread owns column pairs
 // (2t, 2t+1) + 512q and reads them with one 16-byte load; otherwise single columns t + 256q.
 template <bool WANT_J, bool WANT_K, bool VEC>
-__global__ __launch_bounds__(256) void k_jk_stream(int n, int KB, int jsplit,
+__global__ __launch_bounds__(256) void k_jk_stream(int n, int KB, int jsplit, int i0, int ni,
                                                    const double *__restrict__ eri,
                                                    const double *__restrict__ dm,
                                                    double *__restrict__ Jpart,
@@ -33,7 +33,9 @@ __global__ __launch_bounds__(256) void k_jk_stream(int n, int KB, int jsplit,
     __shared__ double T[JK_COLS];
     const size_t N2 = (size_t)n * n;
     const int tid = threadIdx.x;
-    const int i = blockIdx.y / jsplit, js = blockIdx.y - i * jsplit;
+    // rows (i, j) with i in [i0, i0 + ni): `eri` points at row (i0, 0) (the whole matrix when i0 = 0, ni = n;
+    // a rank's row block of the dense-ERI sharding of SURVEY 8(e) otherwise)
+    const int il = blockIdx.y / jsplit, js = blockIdx.y - il * jsplit, i = i0 + il;
     const int jper = (n + jsplit - 1) / jsplit;
     const int jlo = js * jper, jhi = min(n, jlo + jper);
     const int klo = blockIdx.x * KB, khi = min(n, klo + KB);
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void k_jk_stream(int n, int KB, int jsplit,
     }
     for (int j = jlo; j < jhi; ++j) {
         const size_t r = (size_t)i * n + j;
-        const double *row = eri + r * N2 + cbase;
+        const double *row = eri + ((size_t)il * n + j) * N2 + cbase;
         const double dr = WANT_J ? dm[r] : 0.0;
         const double *drow = dm + (size_t)j * n;
         double e[4] = {0, 0, 0, 0};
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void k_jk_stream(int n, int KB, int jsplit,
             double s = 0.0;
             const double *t = &T[tid * n];
             for (int l = 0; l < n; ++l) s += t[l];
-            Kpart[((size_t)js * n + i) * n + klo + tid] = s;
+            Kpart[((size_t)js * ni + il) * n + klo + tid] = s;
         }
     }
 }

@@ -21,9 +21,9 @@ def main(argv=None):
     p.add_argument("--eri", default="auto", choices=["auto", "dense", "cholesky"],
                    help="dense: the nao^4 tensor of grid.py:65; cholesky: factorised J/K; auto: dense while it stays below 8 GB (nao <= 178)")
     p.add_argument("--chol-tol", type=float, default=1e-9)
-    p.add_argument("--eigensolver", default="auto", choices=["auto", "exact", "refine", "subspace"],
-                   help="exact/auto: eigh(F, S) every cycle as dft.py:227; refine: refinement of the previous cycle's "
-                        "eigenvectors on the GPU, subspace: filtered subspace iteration (experiments, full solver as fallback)")
+    p.add_argument("--device-resident", type=int, default=-1,
+                   help="1: Fock build, DIIS, eigh and the density stay in HBM (only scalars cross PCIe per cycle); "
+                        "0: host LAPACK for the eigenproblem; -1 (default): device from 400 basis functions")
     p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 (nccl = RCCL)")
     args = p.parse_args(argv)
 
@@ -60,7 +60,7 @@ def main(argv=None):
     print("Moving data to GPU...")
     try:
         backend = scf.HipBackend(inp, args.functional, args.lib, quirks=bool(args.quirks), rank=rank, world=world, device=device,
-                                 eigensolver=args.eigensolver)
+                                 device_resident=None if args.device_resident < 0 else bool(args.device_resident))
     except Exception as e:  # dft.py:149-153
         print(e)
         sys.exit(1)
@@ -77,11 +77,8 @@ def main(argv=None):
         print("Kernel Statistics (Avg per iter):"); print(f"XC(Exc+Vxc) Time: {res['xc_ms_avg']:.4f} ms")
         print(f"Median per cycle after the first: XC {res['xc_ms']:.4f} ms, J/K {res['jk_ms']:.4f} ms ({args.eri} ERI), "
               f"whole SCF iteration {res['iter_ms']:.4f} ms ({res['cycles']} cycles)")
-        st = getattr(backend.eigh, "stats", None)
-        if st and "refined" in st:
-            print(f"Eigensolver: {st['refined']} cycles by refinement of the previous eigenvectors ({st['steps']} steps), {st['exact']} by full diagonalisation")
-        elif st:
-            print(f"Eigensolver: {st['subspace']} cycles by filtered subspace iteration ({st['passes']} filter passes), {st['exact']} by full diagonalisation")
+        print("Host part of the cycle: " + ("device-resident (Fock build, DIIS, hipSOLVER eigh in HBM)" if backend.device_resident
+                                            else "host LAPACK eigh; [dm|cocc] up and [J|K|Vxc] down in one pinned transfer each"))
         print("-" * 80)
     else:
         print("SCF Unconverged.")

@@ -72,6 +72,59 @@ def vector_bounds(naux, world_size, rank):
     return lo, min(naux, lo + per)
 
 
+def eri_row_bounds(nao, world_size, rank):
+    """Row block [i_lo*nao, i_hi*nao) of the dense (nao^2, nao^2) ERI for `rank`: whole first indices i
+    (so a rank's K rows are complete), contiguous, covering all rows (ERI rows (ij) sharded
+    over the GPUs; the reference keeps the whole matrix on one, dft.py:166)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    per = -(-nao // world_size)
+    i_lo = min(nao, rank * per)
+    i_hi = min(nao, i_lo + per)
+    return i_lo * nao, i_hi * nao
+
+
+class ReplicaSync:
+    """Rank 0 is authoritative for the small replicated state of the SCF loop (dm, cocc, the convergence
+    scalars): it alone runs DIIS + eigh and every other rank receives the result in ONE broadcast per cycle.
+    Replicas therefore cannot drift (different host LAPACK thread counts, different GPUs behind hipSOLVER),
+    and since the stop decision is taken from the broadcast scalars every rank leaves the loop in the same
+    cycle -- no rank is left blocking in the next all-reduce."""
+
+    def __init__(self, device, group=None):
+        self.device, self.group = torch.device(device), group
+
+    def _bcast(self, flat):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return flat
+        if flat.is_cuda and dist.get_backend(self.group) == "gloo":   # rehearsal on one card: gloo moves host memory
+            h = flat.cpu(); dist.broadcast(h, 0, group=self.group); flat.copy_(h)
+        else:
+            dist.broadcast(flat, 0, group=self.group)
+        return flat
+
+    def broadcast(self, tensors):
+        """In place, from rank 0, as one flat message."""
+        flat = self._bcast(torch.cat([t.reshape(-1) for t in tensors]))
+        o = 0
+        for t in tensors:
+            t.copy_(flat[o:o + t.numel()].view_as(t)); o += t.numel()
+
+    def broadcast_numpy(self, arrays):
+        """The same for C-contiguous float64 numpy arrays (host loop): through device memory under RCCL,
+        straight from host memory under gloo."""
+        import torch.distributed as dist
+        ts = [torch.from_numpy(a) for a in arrays]          # views: the arrays are updated in place
+        if dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) != "gloo" and self.device.type == "cuda":
+            dev = [t.to(self.device) for t in ts]
+            self.broadcast(dev)
+            for t, d in zip(ts, dev):
+                t.copy_(d)
+        else:
+            self.broadcast(ts)
+
+
 @dataclass
 class FockParts:
     exc: float

@@ -83,6 +83,8 @@ class DFTSolverWrapper:
         L.DFT_ComputeExchange.restype = None
         L.DFT_ComputeJK.argtypes = [ctypes.c_void_p, ctypes.c_int, _u64, _u64, _u64, _u64]
         L.DFT_ComputeJK.restype = None
+        L.DFT_ComputeJKRows.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u64, _u64, _u64, _u64]
+        L.DFT_ComputeJKRows.restype = ctypes.c_int
         L.DFT_ComputeJKFactorized.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               _u64, _u64, _u64, _u64, _u64]
         L.DFT_ComputeJKFactorized.restype = ctypes.c_int
@@ -150,6 +152,14 @@ class DFTSolverWrapper:
         self.lib.DFT_ComputeJK(self.solver, int(nao), _u64(_ptr(d_eri)), _u64(_ptr(d_dm)),
                                _u64(_ptr(d_J)), _u64(_ptr(d_K)))
         self._check()
+
+    def compute_jk_rows(self, nao, i_lo, i_hi, d_eri_rows, d_dm, d_J, d_K):
+        """J, K from ERI rows (i, j), i_lo <= i < i_hi; d_eri_rows is that row block (first row (i_lo, 0)).
+        Partial J over all columns, rows [i_lo, i_hi) of K: the shares of all blocks add up (all-reduce)."""
+        rc = self.lib.DFT_ComputeJKRows(self.solver, int(nao), int(i_lo), int(i_hi), _u64(_ptr(d_eri_rows)),
+                                        _u64(_ptr(d_dm)), _u64(_ptr(d_J)), _u64(_ptr(d_K)))
+        self._check()
+        return rc
 
     def compute_jk_factorized(self, nao, naux, nocc, d_chol, d_dm, d_cocc, d_J, d_K):
         """J, K from Cholesky vectors d_chol (naux, nao, nao); dm = cocc cocc^T, cocc (nao, nocc).

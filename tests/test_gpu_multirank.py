@@ -1,5 +1,7 @@
 """Two ranks of the SCF driver on ONE GPU (gloo rendezvous on 127.0.0.1): grid block + Cholesky-vector
-slice per rank, one all-reduce of [Vxc | J | K | Exc] per cycle -- same energies as the single-rank run."""
+slice (or dense-ERI row block, DFT_ComputeJKRows) per rank, one all-reduce of [Vxc | J | K | Exc] per cycle,
+rank 0 authoritative for DIIS + eigh (one broadcast of [dm | cocc | scalars]) -- same energies as the
+single-rank run, host and device-resident forms of the loop."""
 import os
 import socket
 import sys
@@ -15,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _rank_main(rank, world, port, fn, eri_mode, out_dir):
+def _rank_main(rank, world, port, fn, eri_mode, out_dir, device_resident=False):
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from quantum_compute_dft_amd import inputs, scf
@@ -23,7 +25,7 @@ def _rank_main(rank, world, port, fn, eri_mode, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         inp = inputs.build("H2O", "def2-svp", 3, verbose=False, eri_mode=eri_mode, chol_tol=1e-10)
-        be = scf.HipBackend(inp, fn, rank=rank, world=world, device="cuda:0")
+        be = scf.HipBackend(inp, fn, rank=rank, world=world, device="cuda:0", device_resident=device_resident)
         res = scf.run_scf(inp, be, fn, log=None, conv_e=1e-11, conv_dm=1e-9)
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), e=res["E_tot"], exc=res["E_xc"], ex=res["E_ex_hf"],
                  dm=res["dm"], conv=res["converged"], ngrid=be.ngrid)
@@ -31,14 +33,15 @@ def _rank_main(rank, world, port, fn, eri_mode, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fn,eri_mode", [("B3LYP", "cholesky"), ("GGA", "dense")])
-def test_two_ranks_on_one_gpu_match_the_single_rank_scf(tmp_path, fn, eri_mode):
+@pytest.mark.parametrize("fn,eri_mode,device_resident", [("B3LYP", "cholesky", False), ("GGA", "dense", False),
+                                                         ("B3LYP", "dense", False), ("B3LYP", "cholesky", True)])
+def test_two_ranks_on_one_gpu_match_the_single_rank_scf(tmp_path, fn, eri_mode, device_resident):
     import torch.multiprocessing as mp
     from quantum_compute_dft_amd import inputs, scf
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no HIP device is visible")
     world = 2
-    mp.spawn(_rank_main, args=(world, _free_port(), fn, eri_mode, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(world, _free_port(), fn, eri_mode, str(tmp_path), device_resident), nprocs=world, join=True)
     inp = inputs.build("H2O", "def2-svp", 3, verbose=False, eri_mode=eri_mode, chol_tol=1e-10)
     ref = scf.run_scf(inp, scf.HipBackend(inp, fn), fn, log=None, conv_e=1e-11, conv_dm=1e-9)
     r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")

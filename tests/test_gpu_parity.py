@@ -249,6 +249,61 @@ def test_coulomb_and_exchange_match_oracle(dev, n):
     assert torch.equal(d_J2, d_J) and torch.equal(d_K2, d_K)   # one-pass form is bit-identical
 
 
+@pytest.mark.parametrize("n,world", [(7, 2), (24, 3), (13, 8), (5, 8)])
+def test_dense_eri_row_blocks_add_up_to_the_whole_contraction(dev, n, world):
+    """DFT_ComputeJKRows on every rank's row block (grid_shard.eri_row_bounds): the partial J's and the K row
+    blocks sum to DFT_ComputeCoulomb / DFT_ComputeExchange of the whole matrix (dft_solver.cu:550-555,
+    dft.py:218) -- what the all-reduce of the sharded SCF cycle does.  More ranks than rows leaves empty blocks."""
+    from quantum_compute_dft_amd.grid_shard import eri_row_bounds
+    rng = np.random.default_rng(300 + n)
+    eri = rng.standard_normal((n * n, n * n))        # not symmetric: pins which index is contracted
+    dm = rng.standard_normal((n, n))
+    J_ref, K_ref = oracle.coulomb(eri, dm), oracle.exchange(eri, dm)
+    w = _solver(2)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    d_dm = t(dm)
+    J_sum, K_sum = np.zeros((n, n)), np.zeros((n, n))
+    covered = 0
+    for r in range(world):
+        lo, hi = eri_row_bounds(n, world, r)
+        covered += hi - lo
+        if hi == lo:
+            continue
+        d_rows = t(eri[lo:hi])
+        d_J = torch.full((n, n), 5.0, dtype=torch.float64, device=dev); d_K = torch.full_like(d_J, 5.0)
+        assert w.compute_jk_rows(n, lo // n, hi // n, d_rows, d_dm, d_J, d_K) == 0
+        torch.cuda.synchronize()
+        K_r = d_K.cpu().numpy()
+        assert np.all(K_r[: lo // n] == 0.0) and np.all(K_r[hi // n:] == 0.0)       # only this block's rows of K
+        J_sum += d_J.cpu().numpy(); K_sum += K_r
+        d_J2 = torch.zeros_like(d_J)
+        assert w.compute_jk_rows(n, lo // n, hi // n, d_rows, d_dm, d_J2, None) == 0   # J alone
+        torch.cuda.synchronize()
+        assert torch.equal(d_J2, d_J)
+    assert covered == n * n
+    assert np.abs(J_sum - J_ref).max() <= 1e-12 * np.abs(J_ref).max() + 1e-14
+    assert np.abs(K_sum - K_ref).max() <= 1e-12 * np.abs(K_ref).max() + 1e-14
+    with pytest.raises(RuntimeError):
+        w.compute_jk_rows(n, 0, n + 1, t(eri), d_dm, d_J, d_K)
+
+
+@pytest.mark.parametrize("fn,eri_mode", [("B3LYP", "dense"), ("GGA", "cholesky")])
+def test_device_resident_scf_matches_the_host_loop(dev, fn, eri_mode):
+    """Fock build, DIIS, eigh (hipSOLVER) and the density stay in HBM; same energies and density
+    as the host-LAPACK form of the loop."""
+    from quantum_compute_dft_amd import inputs, scf
+    inp = inputs.build("H2O", "def2-svp", 3, verbose=False, eri_mode=eri_mode, chol_tol=1e-10)
+    kw = dict(log=None, conv_e=1e-11, conv_dm=1e-9)
+    r_h = scf.run_scf(inp, scf.HipBackend(inp, fn, device_resident=False), fn, **kw)
+    be = scf.HipBackend(inp, fn, device_resident=True)
+    assert be.device_resident and be.eigh.on_device
+    r_d = scf.run_scf(inp, be, fn, **kw)
+    assert r_h["converged"] and r_d["converged"] and abs(r_h["cycles"] - r_d["cycles"]) <= 1
+    assert r_d["E_tot"] == pytest.approx(r_h["E_tot"], abs=1e-9)
+    assert r_d["E_xc"] == pytest.approx(r_h["E_xc"], abs=1e-9)
+    assert np.abs(r_d["dm"] - r_h["dm"]).max() < 1e-7
+
+
 @pytest.mark.parametrize("bname,mol,deriv", [
     ("sto-3g", "O 0 0 0.1173; H 0 0.7572 -0.4692; H 0 -0.7572 -0.4692", 1),
     ("def2-svp", "O 0 0 0.1173; H 0 0.7572 -0.4692; H 0 -0.7572 -0.4692", 1),

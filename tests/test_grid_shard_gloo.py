@@ -121,3 +121,47 @@ def test_two_rank_gloo_fock_parts_match_unsharded(tmp_path):
     assert float(r0["e"]) == pytest.approx(e_ref, rel=1e-13)
     for got, ref in ((r0["v"], v_ref), (r0["J"], J_ref), (r0["K"], K_ref)):
         assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_eri_row_bounds_cover_whole_first_indices():
+    from quantum_compute_dft_amd.grid_shard import eri_row_bounds
+    for nao in (1, 7, 24, 114):
+        for world in (1, 2, 3, 8, 200):
+            blocks = [eri_row_bounds(nao, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == nao * nao
+            assert all(b == c for (_, b), (c, _) in zip(blocks, blocks[1:]))
+            assert all(lo % nao == 0 and hi % nao == 0 for lo, hi in blocks)      # whole i's: a rank's K rows are complete
+
+
+def _eri_worker(rank, world, port, n, out_dir):
+    """Row-sharded dense-ERI J/K under gloo: each rank contracts its row block (numpy restatement of what
+    DFT_ComputeJKRows does on the device), one all-reduce of [J | K]."""
+    from quantum_compute_dft_amd.grid_shard import eri_row_bounds
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(9)
+        eri = rng.standard_normal((n * n, n * n)); dm = rng.standard_normal((n, n))
+        lo, hi = eri_row_bounds(n, world, rank)
+        J = (eri[lo:hi].T @ dm.ravel()[lo:hi]).reshape(n, n)                       # dft_solver.cu:550-555 on a row slice
+        K = np.zeros((n, n))
+        if hi > lo:
+            blk = eri[lo:hi].reshape((hi - lo) // n, n, n, n)                      # (i, j, k, l), i in the block
+            K[lo // n:hi // n] = np.einsum("ijkl,jl->ik", blk, dm)                 # dft.py:218 for these i
+        buf = torch.from_numpy(np.concatenate([J.ravel(), K.ravel()]))
+        dist.all_reduce(buf)
+        np.save(os.path.join(out_dir, f"jk{rank}.npy"), buf.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_row_sharded_dense_jk(tmp_path):
+    world, n = 2, 7
+    mp.spawn(_eri_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(9)
+    eri = rng.standard_normal((n * n, n * n)); dm = rng.standard_normal((n, n))
+    J_ref, K_ref = oracle.coulomb(eri, dm), oracle.exchange(eri, dm)
+    a, b = np.load(tmp_path / "jk0.npy"), np.load(tmp_path / "jk1.npy")
+    assert np.array_equal(a, b)
+    assert np.abs(a[: n * n].reshape(n, n) - J_ref).max() <= 1e-12 * np.abs(J_ref).max()
+    assert np.abs(a[n * n:].reshape(n, n) - K_ref).max() <= 1e-12 * np.abs(K_ref).max()
