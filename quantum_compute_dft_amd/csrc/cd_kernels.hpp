@@ -40,8 +40,15 @@ constexpr int CD_BN = 256, CD_BK = 16, CD_LDB = CD_BN + 16; // 272 = 16 (mod 32)
 // only): tile 64 x 128, 57 KB, TWO workgroups per CU whose prologues, barriers and epilogues
 // interleave -- the half transform's contraction is only nao/16 stages long, so a lone workgroup
 // per CU spends a tenth of its life filling and draining.
-template <int WGM, int MI, bool VECA, bool VECB, bool DOT = false, int NW = 8>
-__global__ __launch_bounds__(64 * NW, 2) void k_gemm_tn(long G, int M, int N, int lda, int ldb,
+// BK = contraction rows per stage, NJ = 16-column MFMA tiles per wave (0 = the defaults above).  The half
+// transform at nocc <= 64 runs <1, MI, ., ., DOT, 4, 8, 4>: wave tile 16 MI x 64, workgroup tile 64 x 256, 8-row
+// stages.  Its MFMA waves also do their own staging, and next to an MFMA in flight a SIMD issues only ~2.6
+// vector/LDS/VMEM (4 scalar) instructions per 64 cycles (tools/coissue_probe*.hip), so what sets the pace is
+// the NON-MFMA instruction count per MFMA: the 16 x 32 wave tile needed 5 LDS reads per 6 MFMAs and ~100
+// other instructions per 24-MFMA stage (57 % MFMA-busy, profiles/r01_pmc_kbuild.json); this one needs 7 reads
+// per 12 MFMAs and ~45 per stage, and at 45 KB of LDS and <= 168 VGPRs (launch bound) THREE workgroups share a CU.
+template <int WGM, int MI, bool VECA, bool VECB, bool DOT = false, int NW = 8, int BK_ = 0, int NJ_ = 0>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && BK_ == 8) ? 3 : 2) void k_gemm_tn(long G, int M, int N, int lda, int ldb,
                                                            const double *__restrict__ A, long strideA,
                                                            const double *__restrict__ B, long strideB,
                                                            long chunk, int nB, int npair, int split,
@@ -51,11 +58,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tn(long G, int M, int N, in
                                                            double *__restrict__ vpart = nullptr,
                                                            int skip_lower = 0)
 {
-    constexpr int THREADS = 64 * NW, CG = THREADS / 16;                  // 16 staging rows x CG column groups
-    constexpr int BM = 64 * WGM, WGN = NW / WGM, NJ = WGM == 2 ? 4 : 2;   // wave tile 16 MI x 16 NJ
+    constexpr int BK = BK_ ? BK_ : CD_BK;
+    constexpr int THREADS = 64 * NW, CG = THREADS / BK;                  // BK staging rows x CG column groups
+    constexpr int BM = 64 * WGM, WGN = NW / WGM, NJ = NJ_ ? NJ_ : (WGM == 2 ? 4 : 2);   // wave tile 16 MI x 16 NJ
     constexpr int BN = 16 * NJ * WGN;                                     // 256 (NW 8) or 128 (NW 4)
     constexpr int LDA_ = BM + 16, LDB_ = BN + 16;                         // = 16 (mod 32)
-    constexpr int ASZ = CD_BK * LDA_, BSZ = CD_BK * LDB_;
+    constexpr int ASZ = BK * LDA_, BSZ = BK * LDB_;
     constexpr int AH = BM / CG / 2;                                       // double2 loads per thread, A tile
     static_assert(BN / CG == 8, "B tile: 8 doubles per thread");
     __shared__ double lds[2 * (ASZ + BSZ)];
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tn(long G, int M, int N, in
         for (int j = 0; j < NJ; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
     if (glo < ghi) {
-        const int nst = (int)((ghi - glo + CD_BK - 1) / CD_BK);
+        const int nst = (int)((ghi - glo + BK - 1) / BK);
         const int s_row = tid / CG, s_cq = tid % CG;
         const unsigned a_voff = (unsigned)(s_row * lda + a0 + 2 * AH * s_cq) * 8u;
         const unsigned b_voff = (unsigned)(s_row * ldb + b0 + 8 * s_cq) * 8u;
@@ -112,24 +120,22 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tn(long G, int M, int N, in
         // less than an HBM round trip under load: with a one-stage prefetch its MFMA pipe was busy
         // 57 % of the time).  Every fetch issues the same number of loads -- stages past the end go
         // through a zero-record descriptor -- so the waits stay counted.
-        double2 ra[2][AH], rb[2][4], rd[2][4];
-        double dot = 0.0;
-        const bool dot_on = DOT && a0 == 0; // uniform
+        double2 ra[2][AH], rb[2][4];
+        // one descriptor per operand for the whole chunk, the stage selected by the SGPR offset of the loads
+        // (range-checked by the hardware; a stage past the end passes the chunk size: every lane out of range,
+        // no traffic, the loads still count in vmcnt).  The host keeps a chunk of either operand below 4 GiB.
+        const __amdgpu_buffer_rsrc_t da = plane_rsrc(A + glo * lda, (ghi - glo) * (long)lda);
+        const __amdgpu_buffer_rsrc_t db = plane_rsrc(B + glo * ldb, (ghi - glo) * (long)ldb);
+        const unsigned a_end = (unsigned)((ghi - glo) * (long)lda * 8), b_end = (unsigned)((ghi - glo) * (long)ldb * 8);
+        const unsigned a_step = (unsigned)(BK * lda) * 8u, b_step = (unsigned)(BK * ldb) * 8u;
         auto fetch = [&](auto S, int st) {
             constexpr int s = decltype(S)::value;
             const bool live = st < nst;
-            const long row0 = glo + (long)min(st, nst - 1) * CD_BK; // < ghi
-            const __amdgpu_buffer_rsrc_t da = plane_tile_rsrc(A, ghi * (long)lda, row0 * lda, live);
-            const __amdgpu_buffer_rsrc_t db = plane_tile_rsrc(B, ghi * (long)ldb, row0 * ldb, live);
+            const unsigned ao = live ? (unsigned)st * a_step : a_end, bo = live ? (unsigned)st * b_step : b_end;
 #pragma unroll
-            for (int h = 0; h < AH; ++h) ra[s][h] = buf_load_pair2<VECA>(da, a_voff + 16 * h, 0);
+            for (int h = 0; h < AH; ++h) ra[s][h] = buf_load_pair2<VECA>(da, a_voff + 16 * h, ao);
 #pragma unroll
-            for (int h = 0; h < 4; ++h) rb[s][h] = buf_load_pair2<VECB>(db, b_voff + 16 * h, 0);
-            if (DOT) { // same rows / columns of the density matrix (ld = ldb = nao)
-                const __amdgpu_buffer_rsrc_t dd = plane_tile_rsrc(Dm, ghi * (long)ldb, row0 * ldb, live && dot_on);
-#pragma unroll
-                for (int h = 0; h < 4; ++h) rd[s][h] = buf_load_pair2<VECB>(dd, b_voff + 16 * h, 0);
-            }
+            for (int h = 0; h < 4; ++h) rb[s][h] = buf_load_pair2<VECB>(db, b_voff + 16 * h, bo);
         };
         auto stash = [&](auto S) { // register set s -> LDS buffer s
             constexpr int s = decltype(S)::value;
@@ -139,20 +145,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tn(long G, int M, int N, in
             double *Bd = Bs + s * BSZ + s_row * LDB_ + 8 * s_cq;
 #pragma unroll
             for (int h = 0; h < 4; ++h) *reinterpret_cast<double2 *>(Bd + 2 * h) = rb[s][h];
-            if (DOT) {
-                const int col = b0 + 8 * s_cq; // columns past N hold the next row's data: masked out
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    dot += (col + 2 * h < N ? rb[s][h].x : 0.0) * rd[s][h].x;
-                    dot += (col + 2 * h + 1 < N ? rb[s][h].y : 0.0) * rd[s][h].y;
-                }
-            }
         };
         auto compute = [&](int buf) {
             const double *Ap = As + buf * ASZ + lk * LDA_ + wm * 64 + li;
             const double *Bp = Bs + buf * BSZ + lk * LDB_ + wn * (16 * NJ) + li;
 #pragma unroll
-            for (int ks = 0; ks < CD_BK / 4; ++ks) {
+            for (int ks = 0; ks < BK / 4; ++ks) {
                 double af[MI], bf[NJ];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = Ap[4 * ks * LDA_ + 16 * i];
@@ -183,16 +181,32 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tn(long G, int M, int N, in
                 lds_barrier();
             }
         }
-        if (DOT && dot_on) { // fixed-order workgroup sum of the threads' partial dots (the tile LDS is free now)
-            __syncthreads(); // every wave is done with the tile buffers
-            lds[tid] = dot;
-            __syncthreads();
-            for (int w = THREADS / 2; w > 0; w >>= 1) {
-                if (tid < w) lds[tid] += lds[tid + w];
-                __syncthreads();
+    }
+
+    if (DOT) {
+        // v_P = L_P : D with D = Cocc Cocc^T is  sum_{i,b} Yt_P[i][b] Cocc[b][i]: a dot of this tile's RESULT with
+        // the (b, i) block of the A operand -- nocc x nao products at the epilogue instead of nao^2 products (and a
+        // second load stream of D tiles) inside the stage loop.  One partial per (P, b-block), fixed order.
+        double dot = 0.0;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int b = b0 + wn * (16 * NJ) + 16 * j + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int a = a0 + wm * 64 + 16 * i + lk + 4 * r;
+                    if (a < M && b < N) dot += acc[i][j][r] * A[(size_t)b * lda + a];
+                }
             }
-            if (tid == 0) vpart[batch * nB + pair % nB] = lds[0];
+        __syncthreads(); // every wave is done with the tile buffers
+        lds[tid] = dot;
+        __syncthreads();
+        for (int w = THREADS / 2; w > 0; w >>= 1) {
+            if (tid < w) lds[tid] += lds[tid + w];
+            __syncthreads();
         }
+        if (tid == 0) vpart[(batch * (long)npair) + pair] = lds[0];
     }
 
     double *out = C + batch * strideC_batch + (long)ck * strideC_chunk;

@@ -436,14 +436,14 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
     hipStream_t st = s->stream;
     const long n2 = (long)nao * nao;
     const int nB = (nao + CD_BN - 1) / CD_BN;
-    // column blocks of the half transform: 128 wide (two 4-wave workgroups per CU) while one 64-row
-    // tile holds all occupied orbitals, 256 wide with 128-row tiles above
-    const int nBh = (K && nocc <= 64) ? (nao + 127) / 128 : nB;
+    // half transform: 64 x 256 tiles (8-row stages, four waves) while one 64-row tile holds all occupied orbitals,
+    // 128 x 256 above; one partial of v_P per tile
+    const int nBh = nB, npair_h = ((nocc + (nocc <= 64 ? 63 : 127)) / (nocc <= 64 ? 64 : 128)) * nBh;
     // v_P = L_P : D.  With K wanted too, the half transform reads every L_P anyway and leaves the
     // partial dots of its tiles (one per 256-column block); otherwise a pass of its own.
     const bool fused_dot = J && K;
     if (J) {
-        if (!reserve(s, s->cdv, sizeof(double) * (size_t)naux * (1 + nBh), "hipMalloc(cd v)")) return -1;
+        if (!reserve(s, s->cdv, sizeof(double) * (size_t)naux * (1 + npair_h), "hipMalloc(cd v)")) return -1;
         if (!fused_dot) {
             ScopedTimer t(s, "cd_dot");
             hipLaunchKernelGGL(k_cd_dot, dim3((unsigned)naux), dim3(256), 0, st, n2, L, dm, (double *)s->cdv.p);
@@ -458,7 +458,8 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
         int live2 = 0; // tiles of K = Yt^T Yt that are computed (the rest are mirrored)
         for (int ia = 0; ia < nA2; ++ia)
             for (int ib = 0; ib < nB; ++ib) live2 += !(128 * ia >= CD_BN * ib + CD_BN);
-        const long per_xcd = s->ksplit > 0 ? s->ksplit : chunks_per_xcd(s, live2, G, sizeof(double) * (size_t)n2);
+        long per_xcd = s->ksplit > 0 ? s->ksplit : chunks_per_xcd(s, live2, G, sizeof(double) * (size_t)n2);
+        while ((double)((G + 8 * per_xcd - 1) / (8 * per_xcd) + CD_BK) * ldy * 8.0 >= 4294967296.0) per_xcd *= 2; // a chunk of Yt stays below 4 GiB (one buffer descriptor)
         const int nslab = (int)(8 * per_xcd);
         long chunk = (G + nslab - 1) / nslab;
         chunk = ((chunk + CD_BK - 1) / CD_BK) * CD_BK;
@@ -476,7 +477,7 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
             hipLaunchKernelGGL(k_pack_cocc, dim3((unsigned)(((long)nao * ldp + 255) / 256)), dim3(256), 0, st, nao, nocc, ldp, cocc, cp);
             // Yt_P (nocc x nao) = Cp^T L_P for every P
 #define QCDFT_HALF3(WGM, MI, VL, DOT, NW)                                                                             \
-    hipLaunchKernelGGL((k_gemm_tn<WGM, MI, true, VL, DOT, NW>), g, dim3(64 * NW), 0, st, (long)nao, nocc, nao, ldp, nao, \
+    hipLaunchKernelGGL((k_gemm_tn<WGM, MI, true, VL, DOT, NW, (WGM == 1 ? 8 : 0), (WGM == 1 ? 4 : 0)>), g, dim3(64 * NW), 0, st, (long)nao, nocc, nao, ldp, nao, \
                        cp, 0L, L, n2, (long)nao, nBh, npair, 0, yt, ldy, (long)nocc * ldy, 0L, dm, vpart)
 #define QCDFT_HALF(WGM, MI, NW)                                                                                       \
     do {                                                                                                              \
@@ -513,7 +514,7 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
         nsl = (naux + pslice - 1) / pslice;
         if (!reserve(s, s->jpart, sizeof(double) * (size_t)nsl * n2, "hipMalloc(cd J slabs)")) return -1;
         double *jp = (double *)s->jpart.p;
-        if (fused_dot) hipLaunchKernelGGL(k_cd_vsum, dim3((unsigned)((naux + 255) / 256)), dim3(256), 0, st, naux, nBh, vpart, v);
+        if (fused_dot) hipLaunchKernelGGL(k_cd_vsum, dim3((unsigned)((naux + 255) / 256)), dim3(256), 0, st, naux, npair_h, vpart, v);
         hipLaunchKernelGGL(k_cd_axpy, dim3((unsigned)eb, (unsigned)nsl), dim3(256), 0, st, n2, naux, pslice, L, v, jp);
         hipLaunchKernelGGL(k_sum_slabs8, dim3((unsigned)((n2 + 31) / 32)), dim3(256), 0, st, (size_t)n2, nsl, (size_t)n2, jp, J);
     }
