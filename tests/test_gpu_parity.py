@@ -180,6 +180,40 @@ def test_low_density_cutoff_points(dev, xc_type):
         _check(exc, v, exc_ref, v_ref)
 
 
+def test_conditioning_aware_bound_on_ill_conditioned_small_bases(dev):
+    """The randomised sweep (tools/fuzz_parity.py, profiles/r01_fuzz_parity.txt) found Vxc differences up to 7e-8
+    relative for B3LYP at nao 2-3: unphysical low-density / high-gradient points of the synthetic grid where LYP is
+    ill-conditioned in rho.  The bound that holds on ANY input is conditioning-aware: the distance to the oracle
+    may not exceed a fixed multiple of the oracle's own response to last-bit perturbations of its inputs (plus the
+    usual 1e-11).  A kernel defect sits orders of magnitude above it and differs between kernel paths."""
+    rng = np.random.default_rng(20261004)
+    worst_ratio, n_hard = 0.0, 0
+    for case in range(120):
+        xc = 2 if case % 3 else 1
+        nao = int(rng.choice([1, 2, 3, 3, 5]))
+        ngrid = int(rng.choice([17, 255, 1000, 4097, 9000]))
+        dm, ao, gr, w = synth_inputs(ngrid, nao, seed=int(rng.integers(1 << 30)))
+        e_ref, v_ref = oracle.compute_xc(xc, dm, ao, w, gr)
+        sens = 0.0
+        for pert in (lambda d, a, g: (d * (1 + 1e-15), a, g), lambda d, a, g: (d, a * (1 + 1e-15), g),
+                     lambda d, a, g: (d, a, g * (1 - 1e-15)), lambda d, a, g: (d * (1 - 2e-15), a * (1 + 1e-15), g)):
+            d2, a2, g2 = pert(dm, ao, gr)
+            sens = max(sens, np.abs(oracle.compute_xc(xc, d2, a2, w, g2)[1] - v_ref).max())
+        scale = np.abs(v_ref).max()
+        errs = []
+        for path in (0, 1):
+            exc, v = _run(_solver(xc, path=path), dm, ao, gr, w, dev)
+            err = np.abs(v - v_ref).max()
+            errs.append(err)
+            assert err <= 1e-11 * scale + 32.0 * sens, (case, xc, nao, ngrid, path, err / scale, sens / scale)
+            assert exc == pytest.approx(e_ref, rel=1e-11)
+        if max(errs) > 1e-11 * scale:
+            n_hard += 1
+            worst_ratio = max(worst_ratio, max(errs) / sens)
+            assert abs(errs[0] - errs[1]) <= 32.0 * sens          # the MFMA and the plain-VALU kernels agree with each other
+    assert worst_ratio <= 32.0
+
+
 def test_determinism_and_chunking_invariance(dev):
     dm, ao, gr, w = synth_inputs(5000, 40, seed=17)
     a = _run(_solver(1), dm, ao, gr, w, dev)
