@@ -151,6 +151,115 @@ def basis_names():
     return sorted(_BASIS_SETS)
 
 
+_L_OF = {"S": 0, "P": 1, "D": 2, "F": 3}
+
+
+def load_basis_file(path, name=None):
+    """Register a basis from a text file in NWChem or Gaussian94 format (what the Basis Set Exchange
+    exports; the reference takes the same data from PySCF's bundled copies, grid.py:45).  General
+    contractions (several coefficient columns) become one shell per column, SP shells an s and a p shell.
+    Returns the registered name.  Tables not shipped here -- def2-SVP for P and S, def2-TZVP beyond H and C:
+    their 10-digit numbers are not reproducible from memory and nothing may be fetched in the build image --
+    come in this way; `check_table` below applies the same invariants to them as to the shipped ones."""
+    table, sym, block = {}, None, None          # block = (kind, rows) being read for element `sym`
+
+    def flush():
+        nonlocal block
+        if block and sym and block[1]:
+            kind, rows = block
+            ncol = max(len(r) for r in rows) - 1
+            for k in range(ncol):
+                l = _L_OF[kind] if kind != "SP" else k      # SP: column 0 -> s, column 1 -> p
+                prims = [(r[0], r[1 + k]) for r in rows if len(r) > 1 + k and r[1 + k] != 0.0]
+                if prims:
+                    table.setdefault(sym, []).append((l, prims))
+        block = None
+
+    num = lambda t: float(t.replace("D", "E").replace("d", "e"))
+    for raw in open(path):
+        line = raw.split("#")[0].split("!")[0].strip()
+        if not line or line.upper().startswith(("BASIS", "END")):
+            continue
+        if line.startswith("****"):
+            flush(); sym = None
+            continue
+        tok = line.split()
+        if block is not None:
+            try:
+                block[1].append([num(t) for t in tok])
+                continue
+            except ValueError:
+                pass
+        flush()
+        head, kinds = tok[0].capitalize(), ("S", "P", "D", "F", "SP")
+        if head.upper() in _Z and len(tok) == 2 and tok[1].upper() in kinds:        # NWChem:     "C    S"
+            sym, block = head, (tok[1].upper(), [])
+        elif head.upper() in _Z and len(tok) == 2 and tok[1] == "0":                # Gaussian94: "C     0"
+            sym = head
+        elif tok[0].upper() in kinds and sym and len(tok) >= 2:                      # Gaussian94: "S   5   1.00"
+            block = (tok[0].upper(), [])
+        else:
+            raise ValueError(f"{path}: cannot parse line {raw!r}")
+    flush()
+    if not table:
+        raise ValueError(f"{path}: no basis functions found")
+    name = (name or os.path.splitext(os.path.basename(path))[0]).lower().replace("_", "-")
+    register_basis(name, table)
+    return name
+
+
+def _radial_matrices(l, exps, coefs_norm, Z):
+    """S, T, V of the one-centre radial problem for primitives r^l exp(-a r^2) (unit-normalised), charge Z."""
+    a = np.asarray(exps)[:, None]; b = np.asarray(exps)[None, :]
+    n = np.array([gto_norm(l, x) for x in exps])
+    nn = n[:, None] * n[None, :]
+    p = a + b
+    S = nn * np.vectorize(gaussian_int)(2 * l + 2, p)
+    # <T> = (2l+3) ab/(a+b) S  for same-l Gaussians;  <1/r> = int r^(2l+1) exp(-p r^2)
+    T = (2 * l + 3) * a * b / p * S
+    V = -Z * nn * np.vectorize(gaussian_int)(2 * l + 1, p)
+    return S, T, V
+
+
+def check_table(sym, shells, pattern=None):
+    """Invariants of one element's table that a typing slip breaks; returns a list of complaints (empty = ok).
+
+    * the contraction pattern is the published one (`pattern`: [(l, nprim), ...]);
+    * exponents are positive and strictly decreasing inside a shell, coefficients non-zero;
+    * the one-electron atom of the same nuclear charge: the lowest eigenvalue of -1/2 lap - Z/r in the span of
+      each l's UNCONTRACTED primitives lies above the exact -Z^2/(2 (l+1)^2) (variational) and, for the occupied
+      angular momenta of the neutral atom, within a few percent of it (a misplaced decimal point in a tight
+      exponent moves it far outside);
+    * the contracted functions of one l are linearly independent (smallest overlap eigenvalue > 1e-6)."""
+    from scipy.linalg import eigh as _eigh
+    Z = atomic_number(sym)
+    bad = []
+    if pattern is not None and sorted((l, len(p)) for l, p in shells) != sorted(pattern):
+        bad.append(f"{sym}: contraction pattern {sorted((l, len(p)) for l, p in shells)} != published {sorted(pattern)}")
+    occupied_l = 0 if Z <= 4 else 1
+    for l in sorted({l for l, _ in shells}):
+        exps = sorted({e for ll, p in shells if ll == l for e, _ in p}, reverse=True)
+        for ll, prims in shells:
+            e = [x for x, _ in prims]
+            if ll == l and (any(x <= 0 for x in e) or any(e[i] <= e[i + 1] for i in range(len(e) - 1)) or any(c == 0 for _, c in prims)):
+                bad.append(f"{sym} l={l}: exponents not positive / strictly decreasing, or a zero coefficient")
+        S, T, V = _radial_matrices(l, exps, None, Z)
+        e0 = float(_eigh(T + V, S, eigvals_only=True)[0])
+        exact = -Z * Z / (2.0 * (l + 1) ** 2)
+        if e0 < exact * (1 + 1e-9):
+            bad.append(f"{sym} l={l}: hydrogenic ground level {e0:.6f} below the exact {exact:.6f}")
+        if l <= occupied_l and e0 > exact * (1 - (0.02 if l == 0 else 0.05)):   # shipped tables: s 0.988-1.000, p 0.969-0.9996 of the exact level
+            bad.append(f"{sym} l={l}: hydrogenic ground level {e0:.6f} too far above the exact {exact:.6f}")
+        # contracted functions of this l
+        cs = [normalized_coefficients(l, [x for x, _ in p], [c for _, c in p]) for ll, p in shells if ll == l]
+        es = [[x for x, _ in p] for ll, p in shells if ll == l]
+        ov = np.array([[sum(ci * cj * gaussian_int(2 * l + 2, a + b) for a, ci in zip(ea, ca) for b, cj in zip(eb, cb))
+                        for eb, cb in zip(es, cs)] for ea, ca in zip(es, cs)])
+        if np.linalg.eigvalsh(ov)[0] < 1e-6:
+            bad.append(f"{sym} l={l}: contracted functions (nearly) linearly dependent")
+    return bad
+
+
 def gaussian_int(n, alpha):
     """int_0^inf r^n exp(-alpha r^2) dr  (PySCF gto.gaussian_int)."""
     n1 = (n + 1) * 0.5
@@ -220,7 +329,8 @@ def build_shells(symbols, coords_bohr, basis="sto-3g"):
     col = 0
     for ia, (sym, r) in enumerate(zip(symbols, coords_bohr)):
         if sym not in table:
-            raise KeyError(f"basis {basis!r} has no entry for element {sym}")
+            raise KeyError(f"basis {basis!r} has no entry for element {sym}: register it with basis.load_basis_file(<NWChem or "
+                           f"Gaussian94 file>, {basis!r}) (dft.py --basis-file) -- tables not reproducible from memory are not shipped")
         for l, prims in sorted(table[sym], key=lambda t: t[0]):  # PySCF orders shells by l
             e = [p[0] for p in prims]
             c = normalized_coefficients(l, e, [p[1] for p in prims])

@@ -15,6 +15,8 @@ def main(argv=None):
     p.add_argument("functional", type=str, choices=["LDA", "GGA", "B3LYP"], help="Functional type")
     p.add_argument("xyzfile", type=str, help="Molecule name (e.g., H2O)")
     p.add_argument("--basis", default="sto-3g")            # grid.py:45 hard-codes sto-3g
+    p.add_argument("--basis-file", default=None, help="NWChem / Gaussian94 basis file (Basis Set Exchange export) to register "
+                                                     "under the --basis name: tables not shipped here (def2-SVP P, S; def2-TZVP N, O ...)")
     p.add_argument("--grid-level", type=int, default=3)   # grid.py:59
     p.add_argument("--quirks", type=int, default=1, help="1: reference formulas as shipped; 0: corrected VWN5/PBE-c derivatives")
     p.add_argument("--lib", default=None, help="path of libdft.so")
@@ -48,6 +50,12 @@ def main(argv=None):
     from .hostinfo import blas_threads
     _pool_pin = blas_threads()   # host BLAS/OpenMP pools on the CPU share from the first numpy call on (hostinfo.py)
     _pool_pin.__enter__()
+    if args.basis_file:
+        from . import basis as _b
+        _b.load_basis_file(args.basis_file, args.basis)
+        for _sym, _sh in _b._BASIS_SETS[args.basis.lower().replace("_", "-")].items():
+            for _msg in _b.check_table(_sym, _sh):
+                print("basis file check:", _msg)
     print(f"=== DFT Solver: {args.functional} | Molecule: {atom_file} ===")
     print("Building CPU data...")
     if args.eri == "auto":

@@ -1,0 +1,91 @@
+"""f1: the basis tables that feed DFT_EvalAO and the integral engine.  PySCF is absent, so the tables
+cannot be diffed against its bundled copies; these are the invariants a typing slip breaks, applied to every
+shipped table and to anything `basis.load_basis_file` brings in (the route for def2-SVP P/S and def2-TZVP N/O,
+whose numbers are not reproducible from memory)."""
+import copy
+
+import numpy as np
+import pytest
+
+from quantum_compute_dft_amd import basis
+
+PATTERNS = {"def2-svp": basis.DEF2_SVP_PATTERN, "def2-tzvp": basis.DEF2_TZVP_PATTERN}
+SHIPPED = [(n, s) for n in ("sto-3g", "def2-svp", "def2-tzvp") for s in basis._BASIS_SETS[n]]
+
+
+@pytest.mark.parametrize("name,sym", SHIPPED)
+def test_shipped_tables_pass_the_invariants(name, sym):
+    pat = PATTERNS.get(name, {}).get(sym)
+    assert basis.check_table(sym, basis._BASIS_SETS[name][sym], pat) == []
+    # published shell / function counts: def2-SVP C [3s2p1d] = 14 functions, def2-TZVP C [5s3p2d1f] = 31
+    counts = {("def2-svp", "H"): 5, ("def2-svp", "C"): 14, ("def2-svp", "N"): 14, ("def2-svp", "O"): 14,
+              ("def2-tzvp", "H"): 6, ("def2-tzvp", "C"): 31, ("sto-3g", "C"): 5, ("sto-3g", "S"): 9}
+    if (name, sym) in counts:
+        assert sum(2 * l + 1 for l, _ in basis._BASIS_SETS[name][sym]) == counts[(name, sym)]
+
+
+@pytest.mark.parametrize("slip", ["decimal_point", "dropped_digit", "order", "zero_coef", "missing_shell"])
+def test_typing_slips_are_caught(slip):
+    t = copy.deepcopy(basis._BASIS_SETS["def2-svp"]["O"])
+    l, prims = t[0]                                     # the contracted 1s
+    if slip == "decimal_point":
+        prims[0] = (prims[0][0] / 10.0, prims[0][1])    # 2266.17... typed as 226.617...
+    elif slip == "dropped_digit":
+        prims[1] = (float(int(prims[1][0]) // 10), prims[1][1])
+    elif slip == "order":
+        prims[0], prims[1] = prims[1], prims[0]
+    elif slip == "zero_coef":
+        prims[2] = (prims[2][0], 0.0)
+    elif slip == "missing_shell":
+        t = t[:-1]
+    assert basis.check_table("O", t, basis.DEF2_SVP_PATTERN["O"]) != []
+
+
+def _write_nwchem(path, table):
+    names = "SPDF"
+    with open(path, "w") as f:
+        f.write('# test export\nBASIS "ao basis" SPHERICAL PRINT\n')
+        for sym, shells in table.items():
+            for l, prims in shells:
+                f.write(f"{sym}    {names[l]}\n")
+                for e, c in prims:
+                    f.write(f"  {e:.10f}   {c:.10f}\n".replace("e", "D") if False else f"  {e!r}   {c!r}\n")
+        f.write("END\n")
+
+
+def _write_gaussian94(path, table):
+    names = "SPDF"
+    with open(path, "w") as f:
+        f.write("! test export\n\n")
+        for sym, shells in table.items():
+            f.write(f"{sym}     0\n")
+            for l, prims in shells:
+                f.write(f"{names[l]}   {len(prims)}   1.00\n")
+                for e, c in prims:
+                    f.write(f"      {e!r}      {str(c).replace('e', 'D')}\n")
+            f.write("****\n")
+
+
+@pytest.mark.parametrize("writer", [_write_nwchem, _write_gaussian94])
+def test_basis_file_round_trip(tmp_path, writer):
+    src = {s: basis._BASIS_SETS["def2-svp"][s] for s in ("H", "C", "O")}
+    path = tmp_path / "my-svp.txt"
+    writer(path, src)
+    name = basis.load_basis_file(str(path), "roundtrip-" + writer.__name__)
+    syms, xyz = basis.parse_xyz("O 0 0 0.1173; H 0 0.7572 -0.4692; H 0 -0.7572 -0.4692; C 2 0 0")
+    a, b = basis.build_shells(syms, xyz, "def2-svp"), basis.build_shells(syms, xyz, name)
+    assert a.nao == b.nao and np.array_equal(a.l, b.l) and np.array_equal(a.exp, b.exp) and np.array_equal(a.coef, b.coef)
+
+
+def test_general_contraction_and_sp_blocks(tmp_path):
+    path = tmp_path / "gc.nw"
+    path.write_text("C    S\n  100.0  0.1  0.0\n  10.0  0.5  0.2\n  1.0  0.6  0.9\nC    SP\n  0.5  1.0  0.7\n  0.2  0.3  0.4\n")
+    name = basis.load_basis_file(str(path), "gc-test")
+    sh = basis._BASIS_SETS[name]["C"]
+    assert [(l, len(p)) for l, p in sh] == [(0, 3), (0, 2), (0, 2), (1, 2)]
+
+
+def test_missing_element_names_the_loader():
+    syms, xyz = basis.parse_xyz("S 0 0 0; H 1.3 0 0; H -0.2 1.3 0")
+    with pytest.raises(KeyError, match="load_basis_file"):
+        basis.build_shells(syms, xyz, "def2-svp")

@@ -123,3 +123,33 @@ def test_def2_tzvp_tables_shape_and_hydrogen_atom():
     sh = basis.build_shells(syms, xyz, "def2-tzvp")
     S, T, V = integrals.int1e(sh, syms, xyz)
     assert eigh(T + V, S, eigvals_only=True)[0] == pytest.approx(-0.499810, abs=2e-6)
+
+
+def test_water_rhf_sto3g_literature_anchor():
+    """A tighter anchor of the integral engine + STO-3G tables than Szabo-Ostlund's four digits: the water
+    molecule of Crawford's "programming projects" (geometry in bohr below; the projects quote
+    E_nuc = 8.002367061810450 and E(RHF/STO-3G) = -74.942079928192).  E_nuc confirms the recalled geometry by
+    itself; the SCF energy then pins S, T, V, the ERIs and the H / O STO-3G tables to ~1e-8 Ha."""
+    from scipy.linalg import eigh
+    from quantum_compute_dft_amd import basis, scf
+    syms = ["O", "H", "H"]
+    xyz = np.array([[0.0, -0.143225816552, 0.0], [1.638036840407, 1.136548822547, 0.0], [-1.638036840407, 1.136548822547, 0.0]])
+    assert integrals.energy_nuc(syms, xyz) == pytest.approx(8.002367061810450, abs=1e-10)
+    sh = basis.build_shells(syms, xyz, "sto-3g")
+    S, T, V = integrals.int1e(sh, syms, xyz)
+    eri = integrals.int2e(sh)
+    H, nocc = T + V, 5
+    e, C = eigh(H, S)
+    dm = 2.0 * C[:, :nocc] @ C[:, :nocc].T
+    diis, E_old = scf.CDIIS(), 0.0
+    for it in range(60):
+        J = np.einsum("ijkl,kl->ij", eri, dm)
+        K = np.einsum("ikjl,kl->ij", eri, dm)
+        F = H + J - 0.5 * K
+        E = 0.5 * float(np.sum(dm * (H + F)))
+        if abs(E - E_old) < 1e-12:
+            break
+        E_old = E
+        e, C = eigh(diis.update(S, dm, F), S)
+        dm = 2.0 * C[:, :nocc] @ C[:, :nocc].T
+    assert E + 8.002367061810450 == pytest.approx(-74.942079928192, abs=2e-8)
