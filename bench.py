@@ -114,72 +114,95 @@ def cpu_baseline(xc, dm, ao, gr, w, target_seconds):
                       f"{threads} threads"}
 
 
-def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=9):
-    """One SCF iteration as dft.py:199-236 does it, on the same synthetic shapes: H2D dm, J (+K for
-    B3LYP), XC sweep, D2H, host Fock build + the dense eigenproblem.  nao <= 200: J/K from one pass
-    over a synthetic dense ERI (the reference's formulation); above, where 8 nao^4 bytes stop being
-    reasonable, from 6 nao synthetic Cholesky vectors (DFT_ComputeJKFactorized).  The eigenproblem
-    runs where scf.FockDiagonaliser puts it (host LAPACK below 400 functions, hipSOLVER above)."""
+def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=9, eri="auto"):
+    """One SCF iteration as dft.py:199-236 does it, on the same synthetic shapes, in the form scf.run_scf uses
+    at that size.  Below 400 functions (host LAPACK eigh): ONE pinned upload [dm | cocc], J (+K for B3LYP), XC
+    sweep, ONE pinned download [J | K | Vxc], Fock build + eigh on the host.  From 400 functions:
+    device-resident -- Fock build, hipSOLVER eigh and dm = cocc cocc^T in HBM, one 4-double download.
+    `eri`: "dense" = one pass over a synthetic dense ERI (the reference's formulation, nao <= 200), "cholesky" =
+    6 nao synthetic Cholesky vectors (DFT_ComputeJKFactorized), "auto" = dense up to 200 functions."""
     from quantum_compute_dft_amd.scf import FockDiagonaliser
+    f64 = torch.float64
     n2 = nao * nao
     nocc = {114: 21, 24: 5, 494: 47, 80: 47, 246: 47, 1150: 250}.get(nao, max(1, nao // 5))  # occupied orbitals of the named molecules
-    dense = nao <= 200
+    dense = (nao <= 200) if eri == "auto" else eri == "dense"
     if dense:
-        eri = torch.randn((n2, n2), dtype=torch.float64, device=dev) * 1e-3
+        d_eri = torch.randn((n2, n2), dtype=f64, device=dev) * 1e-3
         store = 8.0 * n2 * n2
     else:
         naux = int(min(6 * nao, 80e9 / (8.0 * n2)))
-        chol = torch.randn((naux, nao, nao), dtype=torch.float64, device=dev) * 1e-2
-        d_c = torch.zeros((nao, nocc), dtype=torch.float64, device=dev)
+        chol = torch.randn((naux, nao, nao), dtype=f64, device=dev) * 1e-2
         store = 8.0 * naux * n2
+    resident = nao >= 400
     S = np.eye(nao); H = np.diag(np.linspace(-1.0, 1.0, nao))
-    solve = FockDiagonaliser(S, dev)
-    d_J = torch.zeros((nao, nao), dtype=torch.float64, device=dev); d_K = torch.zeros_like(d_J)
-    d_v = torch.zeros_like(d_J); d_dm = dm.clone()
-    dm_h = dm.cpu().numpy()
+    solve = FockDiagonaliser(S, dev, device_from=0 if resident else 400)
+    up = torch.zeros(n2 + nao * nocc, dtype=f64, device=dev)                       # [dm | cocc]
+    d_dm, d_c = up[:n2].view(nao, nao), up[n2:].view(nao, nocc)
+    down = torch.zeros(3 * n2, dtype=f64, device=dev)                               # [J | K | Vxc]
+    d_J, d_K, d_v = (down[k * n2:(k + 1) * n2].view(nao, nao) for k in range(3))
+    pin_up, pin_down = torch.empty(up.shape, dtype=f64).pin_memory(), torch.empty(down.shape, dtype=f64).pin_memory()
     C = np.linalg.qr(np.random.default_rng(SEED).normal(size=(nao, nocc)))[0]
-    pin_dm = torch.empty((nao, nao), dtype=torch.float64).pin_memory()
-    pin_c = torch.empty((nao, nocc), dtype=torch.float64).pin_memory()
-    rows = []
+    cocc_h = np.ascontiguousarray(np.sqrt(2.0) * C); dm_h = cocc_h @ cocc_h.T
     want_k = xc == "B3LYP"
+    if resident:
+        Hd = torch.as_tensor(H, dtype=f64, device=dev); X = solve.X
+        cocc = torch.as_tensor(cocc_h, dtype=f64, device=dev); dmd = cocc @ cocc.T
+    rows = []
     pin = blas_threads(1 if nao < 400 else None); pin.__enter__()   # as scf.run_scf pins the host pools
-    for it in range(iters + 1):
-        t0 = time.perf_counter()
-        pin_dm.copy_(torch.as_tensor(dm_h)); d_dm.copy_(pin_dm, non_blocking=True)      # pinned staging, as scf.HipBackend
-        if not dense:
-            pin_c.copy_(torch.as_tensor(np.ascontiguousarray(np.sqrt(2.0) * C[:, :nocc]))); d_c.copy_(pin_c, non_blocking=True)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
+
+    def device_parts():
         if not dense:
             solver.compute_jk_factorized(nao, naux, nocc, chol, d_dm, d_c if want_k else None, d_J, d_K if want_k else None)
         elif want_k:
-            solver.compute_jk(nao, eri, d_dm, d_J, d_K)
+            solver.compute_jk(nao, d_eri, d_dm, d_J, d_K)
         else:
-            solver.compute_coulomb(nao, eri, d_dm, d_J)
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        solver.compute_xc(ngrid, nao, d_dm, ao, w, d_v, gr); t3 = time.perf_counter()
-        J = d_J.cpu().numpy(); V = d_v.cpu().numpy(); K = d_K.cpu().numpy() if want_k else 0.0
-        t4 = time.perf_counter()
-        F = H + 1e-3 * (J + 0.5 * (V + V.T) - 0.1 * K)
-        e, C = solve(F); dm_new = 2.0 * C[:, :nocc] @ C[:, :nocc].T
+            solver.compute_coulomb(nao, d_eri, d_dm, d_J)
+        torch.cuda.synchronize(); t_jk = time.perf_counter()
+        solver.compute_xc(ngrid, nao, d_dm, ao, w, d_v, gr)
+        return t_jk, time.perf_counter()
+
+    for it in range(iters + 1):
+        t0 = time.perf_counter()
+        if resident:
+            d_dm.copy_(dmd); d_c.copy_(cocc)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            t2, t3 = device_parts()
+            t4 = t3
+            F = Hd + 1e-3 * (d_J + 0.5 * (d_v + d_v.T) - (0.1 * d_K if want_k else 0.0))
+            e, Cp = torch.linalg.eigh(X.T @ F @ X)
+            cocc = (X @ Cp[:, :nocc]) * float(np.sqrt(2.0)); dm_new = cocc @ cocc.T
+            scal = torch.stack([(dm_new * Hd).sum(), (dm_new * d_J).sum(), (dm_new * d_K).sum(), torch.linalg.norm(dm_new - dmd)]).tolist()
+            dmd = dm_new
+        else:
+            pin_up[:n2].copy_(torch.as_tensor(dm_h).reshape(-1)); pin_up[n2:].copy_(torch.as_tensor(cocc_h).reshape(-1))
+            up.copy_(pin_up, non_blocking=True)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            t2, t3 = device_parts()
+            pin_down.copy_(down, non_blocking=True); torch.cuda.synchronize()
+            hd = pin_down.numpy()
+            J, K, V = (hd[k * n2:(k + 1) * n2].reshape(nao, nao) for k in range(3))
+            t4 = time.perf_counter()
+            F = H + 1e-3 * (J + 0.5 * (V + V.T) - (0.1 * K if want_k else 0.0))
+            e, Cf = solve(F)
+            cocc_h = np.ascontiguousarray(np.sqrt(2.0) * Cf[:, :nocc]); dm_h = cocc_h @ cocc_h.T
         t5 = time.perf_counter()
-        if os.environ.get("QCDFT_BENCH_DEBUG"):
-            print(f"[scf_iteration {it}] h2d {1e3*(t1-t0):.2f} jk {1e3*(t2-t1):.2f} xc {1e3*(t3-t2):.2f} d2h {1e3*(t4-t3):.2f} host {1e3*(t5-t4):.2f} ms", file=sys.stderr, flush=True)
         if it:  # first iteration warms allocations
             rows.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5 - t0))
     # medians: a 16-core share of a 256-core host stalls a cycle for tens of ms now and then (seen: one
     # 24 ms host part among 15 cycles of 0.7 ms); the worst cycle is reported next to them
     med = 1e3 * np.median(np.array(rows), axis=0)
-    parts = dict(zip(("h2d", "jk", "xc", "d2h", "host_eigh"), (float(v) for v in med[:5])))
+    parts = dict(zip(("upload", "jk", "xc", "download", "fock_eigh_density"), (float(v) for v in med[:5])))
     t_all, t_worst = float(med[5]), 1e3 * max(r[5] for r in rows)
     pin.__exit__(None, None, None)
     if dense:
-        del eri
+        del d_eri
     else:
         del chol
     torch.cuda.empty_cache()
     how = ("one pass over a synthetic dense ERI" if dense else f"{naux} synthetic Cholesky vectors (factorised)")
     return {"ms": t_all, "parts_ms": parts, "statistic": f"median of {iters} cycles", "worst_cycle_ms": t_worst, "eri_bytes": store,
-            "eigh": "hipSOLVER on the device" if solve.on_device else "host LAPACK (scipy)",
+            "form": "device-resident: Fock build, eigh (hipSOLVER), density in HBM; scalars only cross PCIe" if resident
+                    else "host LAPACK eigh; [dm|cocc] up and [J|K|Vxc] down in one pinned transfer each",
             "note": "synthetic dm; J" + ("+K" if want_k else "") + f" from {how}, XC, Fock build + eigh as in dft.py:199-236"}
 
 
@@ -514,6 +537,7 @@ def main():
         if world == 1 and not strong and not args.no_extra_legs:
             line["ao_sweep"] = ao_sweep_leg(lib_path, dev)
             line["scf_iteration"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev)
+            line["scf_iteration_factorised_j"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, eri="cholesky")
             del ao, gr
             torch.cuda.empty_cache()
             xa, na, ga = WORKLOADS["anthracene_b3lyp_def2tzvp"]

@@ -197,12 +197,18 @@ __global__ __launch_bounds__(W16_THREADS) void k_vxc_ws16(long ngrid, int nao,
                         if (c < C::NCOL) {
                             const double a0 = p0[set][2 * j], b0 = p0[set][2 * j + 1];
                             double qa = k0[set] * a0, qb = k0[set] * b0;
-                            if (GRAD) {
+                            if (GRAD && !(dbg & 64)) {
                                 qa += k1[set] * p1[set][2 * j] + k2[set] * p2[set][2 * j] + k3[set] * p3[set][2 * j];
                                 qb += k1[set] * p1[set][2 * j + 1] + k2[set] * p2[set][2 * j + 1] + k3[set] * p3[set][2 * j + 1];
+                            } else if (GRAD) { // diagnostics: no fp64 FMAs, the gradient registers only kept alive
+                                asm volatile("" ::"v"(p1[set][2 * j]), "v"(p2[set][2 * j]), "v"(p3[set][2 * j]), "v"(p1[set][2 * j + 1]), "v"(p2[set][2 * j + 1]), "v"(p3[set][2 * j + 1]));
                             }
-                            *reinterpret_cast<double2 *>(&Q[row * C::LDX + c]) = make_double2(qa, qb);
-                            *reinterpret_cast<double2 *>(&P[row * C::LDX + c]) = make_double2(a0, b0);
+                            if (!(dbg & 8)) {
+                                *reinterpret_cast<double2 *>(&Q[row * C::LDX + c]) = make_double2(qa, qb);
+                                *reinterpret_cast<double2 *>(&P[row * C::LDX + c]) = make_double2(a0, b0);
+                            } else { // diagnostics: no LDS writes
+                                asm volatile("" ::"v"(qa), "v"(qb), "v"(a0), "v"(b0));
+                            }
                         }
                     }
                 issue(set, (unsigned)step + 2u);

@@ -13,7 +13,7 @@ d_v = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
 s = q.DFTSolverWrapper(q.library_path(), xc)
 for waves in (16, 8):
     s.set_option("ws_waves", waves)
-    for dbg in ((0, 1, 32, 34) if waves == 16 else (0,)):
+    for dbg in ((0, 1, 32, 8, 9, 64, 65, 72, 73) if waves == 16 else (0,)):
         s.set_option("dbg", dbg); s.set_option("profile", 1)
         acc = {}
         for r in range(6):
