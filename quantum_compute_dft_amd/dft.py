@@ -26,6 +26,10 @@ def main(argv=None):
     p.add_argument("--device-resident", type=int, default=-1,
                    help="1: Fock build, DIIS, eigh and the density stay in HBM (only scalars cross PCIe per cycle); "
                         "0: host LAPACK for the eigenproblem; -1 (default): device from 400 basis functions")
+    p.add_argument("--both-quirks", action="store_true",
+                   help="LDA/GGA: run the SCF twice, with the reference's formulas as shipped (its CUDA path) and with the "
+                        "corrected VWN5 / PBE-c derivatives (what PySCF's slater,vwn5 / PBE,PBE compute), and report both energies")
+    p.add_argument("--json", default=None, help="also append the run's one-line JSON record to this file")
     p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 (nccl = RCCL)")
     args = p.parse_args(argv)
 
@@ -74,6 +78,11 @@ def main(argv=None):
         sys.exit(1)
     print(f"GPU Init Time: {backend.init_time:.4f}s" + (f"  ({world} ranks: grid block + Cholesky-vector slice per GPU)" if world > 1 else ""))
     res = scf.run_scf(inp, backend, args.functional)
+    other = None
+    if args.both_quirks and args.functional != "B3LYP":   # B3LYP's four components are derivative-correct: one answer
+        backend.solver.set_option("quirks", 0 if args.quirks else 1)
+        other = scf.run_scf(inp, backend, args.functional, log=None)
+        backend.solver.set_option("quirks", 1 if args.quirks else 0)
     if res["converged"]:
         print("-" * 80); print("Converged!")
         print(f"Total Energy: {res['E_tot']:.8f} Ha"); print(f"E_one       : {res['E_one']:.8f} Ha")
@@ -90,6 +99,25 @@ def main(argv=None):
         print("-" * 80)
     else:
         print("SCF Unconverged.")
+    if other is not None:
+        a, b = ("reference formulas as shipped", "corrected derivatives") if args.quirks else ("corrected derivatives", "reference formulas as shipped")
+        print(f"Total Energy, {a:32s}: {res['E_tot']:.8f} Ha   (this run; --quirks {args.quirks})")
+        print(f"Total Energy, {b:32s}: {other['E_tot']:.8f} Ha   (difference {res['E_tot'] - other['E_tot']:+.2e} Ha)")
+    import json
+    record = {"functional": args.functional, "molecule": os.path.splitext(atom_file)[0], "basis": args.basis, "grid_level": args.grid_level,
+              "nao": int(inp.shells.nao), "ngrid": int(inp.grids.size), "nocc": int(inp.nocc), "n_gpus": world, "eri": args.eri,
+              "quirks": int(args.quirks), "converged": bool(res["converged"]), "cycles": int(res.get("cycles", 0)),
+              "E_tot": res.get("E_tot"), "E_one": res.get("E_one"), "E_coul": res.get("E_coul"), "E_xc": res.get("E_xc"),
+              "E_ex_hf": res.get("E_ex_hf"), "E_nuc": float(inp.E_nuc), "total_time_s": res.get("total_time"),
+              "xc_ms_avg": res.get("xc_ms_avg"), "xc_ms": res.get("xc_ms"), "jk_ms": res.get("jk_ms"), "iter_ms": res.get("iter_ms"),
+              "gpu_init_s": backend.init_time, "device_resident": bool(backend.device_resident)}
+    if other is not None:
+        record["E_tot_other_quirks"] = other.get("E_tot"); record["other_quirks"] = 0 if args.quirks else 1
+    line = json.dumps(record)
+    print(line)                                  # one JSON line per run for a harness
+    if args.json and not rank:
+        with open(args.json, "a") as fh:
+            fh.write(line + "\n")
 
     if world > 1:
         import torch.distributed as dist
