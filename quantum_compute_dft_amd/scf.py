@@ -216,6 +216,7 @@ class HipBackend:
                 self.d_K.copy_(parts.K)
             return parts.exc, time.time() - t0
         self._jk_device(want_k)
+        self.torch.cuda.synchronize()      # J/K are asynchronous: without this the XC bracket below would include them
         t0 = time.time()
         exc = self._xc_device()
         return exc, time.time() - t0
