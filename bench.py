@@ -201,7 +201,9 @@ def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=9, eri="a
     torch.cuda.empty_cache()
     how = ("one pass over a synthetic dense ERI" if dense else f"{naux} synthetic Cholesky vectors (factorised)")
     return {"ms": t_all, "parts_ms": parts, "statistic": f"median of {iters} cycles", "worst_cycle_ms": t_worst, "eri_bytes": store,
-            "form": "device-resident: Fock build, eigh (hipSOLVER), density in HBM; scalars only cross PCIe" if resident
+            "form": "device-resident: Fock build, eigh (hipSOLVER syevd EVERY cycle: the synthetic Fock sequence says nothing about an "
+                    "SCF trajectory; the driver's occupied-subspace rotation takes the real Anthracene/def2-TZVP cycle from 23.5 to "
+                    "15.7 ms, profiles/r02_eigensolver.txt), density in HBM; scalars only cross PCIe" if resident
                     else "host LAPACK eigh; [dm|cocc] up and [J|K|Vxc] down in one pinned transfer each",
             "note": "synthetic dm; J" + ("+K" if want_k else "") + f" from {how}, XC, Fock build + eigh as in dft.py:199-236"}
 

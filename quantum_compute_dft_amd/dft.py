@@ -23,6 +23,10 @@ def main(argv=None):
     p.add_argument("--eri", default="auto", choices=["auto", "dense", "cholesky"],
                    help="dense: the nao^4 tensor of grid.py:65; cholesky: factorised J/K; auto: dense while it stays below 8 GB (nao <= 178)")
     p.add_argument("--chol-tol", type=float, default=1e-9)
+    p.add_argument("--eigensolver", default="auto", choices=["auto", "rotate", "exact"],
+                   help="exact: eigh(F, S) every cycle as dft.py:227; rotate: occupied-subspace rotation from the previous cycle's "
+                        "orbitals, full solver as first cycle and fallback; auto (default): rotate in the device-resident loop "
+                        "(from 400 basis functions), exact below")
     p.add_argument("--device-resident", type=int, default=-1,
                    help="1: Fock build, DIIS, eigh and the density stay in HBM (only scalars cross PCIe per cycle); "
                         "0: host LAPACK for the eigenproblem; -1 (default): device from 400 basis functions")
@@ -72,7 +76,8 @@ def main(argv=None):
     print("Moving data to GPU...")
     try:
         backend = scf.HipBackend(inp, args.functional, args.lib, quirks=bool(args.quirks), rank=rank, world=world, device=device,
-                                 device_resident=None if args.device_resident < 0 else bool(args.device_resident))
+                                 device_resident=None if args.device_resident < 0 else bool(args.device_resident),
+                                 eigensolver=args.eigensolver)
     except Exception as e:  # dft.py:149-153
         print(e)
         sys.exit(1)
@@ -94,6 +99,9 @@ def main(argv=None):
         print("Kernel Statistics (Avg per iter):"); print(f"XC(Exc+Vxc) Time: {res['xc_ms_avg']:.4f} ms")
         print(f"Median per cycle after the first: XC {res['xc_ms']:.4f} ms, J/K {res['jk_ms']:.4f} ms ({args.eri} ERI), "
               f"whole SCF iteration {res['iter_ms']:.4f} ms ({res['cycles']} cycles)")
+        if backend.occ_solver is not None:
+            st = backend.occ_solver.stats
+            print(f"Eigensolver: {st['rotated']} cycles by occupied-subspace rotation ({st['inner_steps']} fixed-point steps), {st['exact']} by full diagonalisation")
         print("Host part of the cycle: " + ("device-resident (Fock build, DIIS, hipSOLVER eigh in HBM)" if backend.device_resident
                                             else "host LAPACK eigh; [dm|cocc] up and [J|K|Vxc] down in one pinned transfer each"))
         print("-" * 80)
@@ -110,7 +118,8 @@ def main(argv=None):
               "E_tot": res.get("E_tot"), "E_one": res.get("E_one"), "E_coul": res.get("E_coul"), "E_xc": res.get("E_xc"),
               "E_ex_hf": res.get("E_ex_hf"), "E_nuc": float(inp.E_nuc), "total_time_s": res.get("total_time"),
               "xc_ms_avg": res.get("xc_ms_avg"), "xc_ms": res.get("xc_ms"), "jk_ms": res.get("jk_ms"), "iter_ms": res.get("iter_ms"),
-              "gpu_init_s": backend.init_time, "device_resident": bool(backend.device_resident)}
+              "gpu_init_s": backend.init_time, "device_resident": bool(backend.device_resident), "eigensolver": args.eigensolver,
+              "eigensolver_stats": dict(backend.occ_solver.stats) if backend.occ_solver is not None else None}
     if other is not None:
         record["E_tot_other_quirks"] = other.get("E_tot"); record["other_quirks"] = 0 if args.quirks else 1
     line = json.dumps(record)

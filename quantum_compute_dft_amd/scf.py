@@ -114,6 +114,104 @@ class FockDiagonaliser:
         return e.cpu().numpy(), (self.X @ Cp).cpu().numpy()
 
 
+class OccupiedRotation:
+    """The occupied orbitals of F C = S C e WITHOUT a dense eigensolve per cycle.
+
+    The SCF loop only consumes the occupied subspace (dm = 2 C_occ C_occ^T, dft.py:182,228), and between two
+    cycles the Fock matrix moves little.  A full S-orthonormal basis U = [U_o | U_v] is kept from the last full
+    diagonalisation; each cycle forms A = U^T F U (two n^3 GEMMs, the only n^3 work) and finds the rotation that
+    decouples the two blocks: with K (n_virt x n_occ) solving the Riccati equation
+
+        A_vo + A_vv K - K A_oo - K A_ov K = 0
+
+    the columns of U_o + U_v K span the new occupied space exactly.  K is found by the diagonally preconditioned
+    fixed point K <- K - R / (a_v - a_o) -- denominators only ACROSS the gap, so near-degenerate orbitals inside
+    either block (Benzene's e pairs, the dense virtual spectrum of a TZVP basis) never enter, which is what
+    defeated the refinement and filtering attempts of round 1 -- at O(n_virt^2 n_occ) per step.  The orthogonal
+    completion  U_o' = (U_o + U_v K)(1 + K^T K)^-1/2,  U_v' = (U_v - U_o K^T)(1 + K K^T)^-1/2  needs only the
+    n_occ x n_occ eigen-decomposition of K^T K; the occupied block is then made canonical (an n_occ x n_occ eigh), so
+    its side of the next cycle's denominators is exact.  Falls back to the full solver (which also does the first
+    cycle) when the first-order rotation exceeds 0.5, the fixed point has not reached `tol` in `max_inner` steps or
+    grows, or the aufbau order is in doubt (highest occupied level within 1e-3 Ha of the lowest virtual diagonal).
+
+    Where it pays (profiles/r02_eigensolver.txt): the fixed point needs 15-20 steps in the middle of an SCF run (the
+    Fock matrix still moves by 1e-2) and 4-6 at its end, each a handful of small GEMMs.  On the device at n = 494
+    that is ~2 ms against 11.4 ms for hipSOLVER's syevd; at n = 114 / 246 on one host thread it is no faster than
+    dsyevd (0.65 / 3.2 ms), so `eigensolver="auto"` uses it only in the device-resident loop (from 400 functions).
+    Same converged energies to 1e-10 Ha and the same cycle counts as the exact loop (tests/test_scf_cpu.py)."""
+
+    def __init__(self, S, nocc, device=None, tol=1e-10, max_inner=60):
+        import torch
+        self.t, self.no, self.tol, self.max_inner = torch, int(nocc), tol, max_inner
+        self.dev = torch.device(device) if device is not None else torch.device("cpu")
+        s, V = np.linalg.eigh(S)
+        self.X = torch.as_tensor(V / np.sqrt(s), dtype=torch.float64, device=self.dev)   # S^-1/2 (columns)
+        self.U = None
+        self.stats = {"exact": 0, "rotated": 0, "inner_steps": 0}
+
+    def _exact(self, F):
+        t = self.t
+        Fp = self.X.T @ F @ self.X
+        if self.dev.type == "cpu":      # one LAPACK thread beats hipSOLVER below ~400 functions (FockDiagonaliser)
+            e, Cp = eigh(Fp.numpy(), driver="evd")
+            e, Cp = t.from_numpy(e), t.from_numpy(Cp)
+        else:
+            e, Cp = t.linalg.eigh(Fp)
+        self.U = self.X @ Cp
+        self.stats["exact"] += 1
+        return e, self.U[:, :self.no]
+
+    def occupied(self, F):
+        """(orbital energies, C_occ (n, nocc)) for the Fock matrix F (numpy array or tensor on self.dev); the
+        energies are exact for the occupied block, diagonal estimates for the virtual one after a rotation."""
+        t, no = self.t, self.no
+        F = F if t.is_tensor(F) else t.as_tensor(F, dtype=t.float64, device=self.dev)
+        if self.U is None or no == 0 or no == F.shape[0]:
+            return self._exact(F)
+        U = self.U
+        A = U.T @ (F @ U)
+        d = t.diagonal(A)
+        do, dv = d[:no], d[no:]
+        Aoo, Aov, Avo, Avv = A[:no, :no], A[:no, no:], A[no:, :no], A[no:, no:]
+        den = dv[:, None] - do[None, :]
+        K = -Avo / den
+        if float(K.abs().max()) > 0.5:
+            return self._exact(F)
+        prev, ok = float("inf"), False
+        every = 1 if self.dev.type == "cpu" else 3      # on the device a convergence test is a host sync: every third step
+        for it in range(self.max_inner):
+            R = Avo + Avv @ K - K @ Aoo - K @ (Aov @ K)
+            self.stats["inner_steps"] += 1
+            if it % every == 0:
+                r = float(R.abs().max())
+                if r < self.tol:
+                    ok = True
+                    break
+                if not (r < 4.0 * prev):    # diverging (or NaN)
+                    break
+                prev = min(prev, r)
+            K = K - R / den
+        if not ok:
+            return self._exact(F)
+        lam, V = t.linalg.eigh(K.T @ K)
+        lam = lam.clamp_min(0.0)
+        Mo = (V / t.sqrt(1.0 + lam)) @ V.T                                    # (1 + K^T K)^-1/2
+        g = t.where(lam > 1e-12, (1.0 / t.sqrt(1.0 + lam) - 1.0) / lam.clamp_min(1e-300), t.full_like(lam, -0.5))
+        G = (V * g) @ V.T                                                     # (1 + K K^T)^-1/2 = 1 + K G K^T
+        Uo, Uv = U[:, :no], U[:, no:]
+        T = Uv - Uo @ K.T
+        Uv2 = T + ((T @ K) @ G) @ K.T
+        Uo2 = (Uo + Uv @ K) @ Mo
+        Aoo2 = Mo @ (Aoo + Aov @ K + K.T @ Avo + K.T @ (Avv @ K)) @ Mo        # occupied block in the rotated basis
+        eo, Vo = t.linalg.eigh(0.5 * (Aoo2 + Aoo2.T))
+        if float(eo[-1]) > float(dv.min()) - 1e-3:                            # aufbau order in doubt
+            return self._exact(F)
+        Uo2 = Uo2 @ Vo                                                        # canonical occupied orbitals
+        self.U = t.cat([Uo2, Uv2], dim=1)
+        self.stats["rotated"] += 1
+        return t.cat([eo, dv]), Uo2
+
+
 class HipBackend:
     """Device side of the loop: libdft.so through DFTSolverWrapper, torch tensors as buffers.
 
@@ -125,7 +223,7 @@ class HipBackend:
     rows of J (and, through the (i,k) view, its partial K); the all-reduce assembles them."""
 
     def __init__(self, inp, functional, lib_path=None, quirks=True, rank=0, world=1, device=None, group=None,
-                 device_resident=None, device_from=400):
+                 device_resident=None, device_from=400, eigensolver="auto"):
         import torch
         from .build import library_path
         from .grid_shard import ReplicaSync, ShardedFock, eri_row_bounds, shard_bounds, vector_bounds
@@ -178,7 +276,14 @@ class HipBackend:
         self.replica_sync = ReplicaSync(self.dev, group) if world > 1 else None
         if world > 1:
             self._sharded = ShardedFock(nao, self._local_sweep, self._local_jk, self.dev, group)
+        # "exact": eigh(F, S) every cycle, the reference's loop (dft.py:227); "rotate": occupied-subspace rotation with
+        # the full solver as first cycle and fallback; "auto": rotate where it pays -- the device-resident loop
         self.eigh = FockDiagonaliser(inp.S, self.dev, device_from=0 if self.device_resident else device_from)
+        self.occ_solver = None
+        if eigensolver not in ("auto", "rotate", "exact"):
+            raise ValueError(f"eigensolver {eigensolver!r}: expected 'auto', 'rotate' or 'exact'")
+        if eigensolver == "rotate" or (eigensolver == "auto" and self.device_resident and nao >= device_from):
+            self.occ_solver = OccupiedRotation(inp.S, inp.nocc, self.dev if self.device_resident else None)
         torch.cuda.synchronize()
         self.init_time = time.time() - t0
 
@@ -291,9 +396,18 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     Hcore, S, nocc = inp.Hcore, inp.S, inp.nocc
     root = getattr(backend, "rank", 0) == 0
     sync = getattr(backend, "replica_sync", None)
-    solve = getattr(backend, "eigh", None) or (lambda F: eigh(F, S))
+    solve_full = getattr(backend, "eigh", None) or (lambda F: eigh(F, S))
+    occ = getattr(backend, "occ_solver", None)
+
+    def solve(F):   # (orbital energies, C_occ): the loop never uses the virtual orbitals (dft.py:182,228)
+        if occ is not None:
+            e_, co_ = occ.occupied(F)
+            return e_.numpy(), co_.numpy()
+        e_, C_ = solve_full(F)
+        return e_, C_[:, :nocc]
+
     e, C = solve(Hcore)                                                                # dft.py:181
-    cocc = np.ascontiguousarray(np.sqrt(2.0) * C[:, :nocc])
+    cocc = np.ascontiguousarray(np.sqrt(2.0) * C)
     dm = cocc @ cocc.T                                                                 # = 2 C_occ C_occ^T, dft.py:182
     if sync:
         sync.broadcast_numpy([dm, cocc])                                               # replicas start from rank 0's guess
@@ -319,7 +433,7 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
             F = Hcore + J + Vxc - (c_hf * 0.5 * K if K is not None else 0.0)           # dft.py:221,223
             F = diis.update(S, dm, F)
             e, C = solve(F)
-            cocc_new = np.ascontiguousarray(np.sqrt(2.0) * C[:, :nocc])
+            cocc_new = np.ascontiguousarray(np.sqrt(2.0) * C)
             dm_new = cocc_new @ cocc_new.T
             scal = np.array([np.sum(dm_new * Hcore), 0.5 * np.sum(dm_new * J),
                              -0.25 * c_hf * np.sum(dm_new * K) if K is not None else 0.0,
@@ -355,6 +469,9 @@ def _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     sqrt2 = float(np.sqrt(2.0))
 
     def eigh_occ(F):                                                                   # dft.py:181,227 on the device
+        if backend.occ_solver is not None:
+            e, co = backend.occ_solver.occupied(F)
+            return e, co * sqrt2
         e, Cp = t.linalg.eigh(X.T @ F @ X)
         return e, (X @ Cp[:, :nocc]) * sqrt2
 

@@ -330,8 +330,14 @@ def test_device_resident_scf_matches_the_host_loop(dev, fn, eri_mode):
     kw = dict(log=None, conv_e=1e-11, conv_dm=1e-9)
     r_h = scf.run_scf(inp, scf.HipBackend(inp, fn, device_resident=False), fn, **kw)
     be = scf.HipBackend(inp, fn, device_resident=True)
-    assert be.device_resident and be.eigh.on_device
+    assert be.device_resident and be.eigh.on_device and be.occ_solver is None   # "auto": rotation only from 400 functions
     r_d = scf.run_scf(inp, be, fn, **kw)
+    # the occupied-subspace rotation forced on, on the device: same loop again
+    be_r = scf.HipBackend(inp, fn, device_resident=True, eigensolver="rotate")
+    r_r = scf.run_scf(inp, be_r, fn, **kw)
+    assert r_r["converged"] and abs(r_r["cycles"] - r_h["cycles"]) <= 3 and be_r.occ_solver.stats["rotated"] >= 3
+    assert r_r["E_tot"] == pytest.approx(r_h["E_tot"], abs=1e-9)
+    assert np.abs(r_r["dm"] - r_h["dm"]).max() < 1e-7
     assert r_h["converged"] and r_d["converged"] and abs(r_h["cycles"] - r_d["cycles"]) <= 1
     assert r_d["E_tot"] == pytest.approx(r_h["E_tot"], abs=1e-9)
     assert r_d["E_xc"] == pytest.approx(r_h["E_xc"], abs=1e-9)

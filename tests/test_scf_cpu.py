@@ -37,6 +37,51 @@ def test_reference_derivative_quirks_shift_converged_energies(water):
         assert lo < abs(a - b) < hi, (fn, a - b)
 
 
+@pytest.mark.parametrize("mol,bname,fn,level", [("H2O", "def2-svp", "B3LYP", 1), ("H2O", "def2-svp", "GGA", 1), ("Benzene", "sto-3g", "B3LYP", 1)])
+def test_occupied_rotation_reproduces_the_exact_loop(mol, bname, fn, level):
+    """scf.OccupiedRotation (Riccati rotation of the previous cycle's occupied space, full solver as first cycle and
+    fallback) in place of eigh(F, S) every cycle (dft.py:227): same converged energy and density to 1e-9, same cycle
+    count within one, and most cycles without a dense eigensolve -- incl. Benzene, whose degenerate e pairs sit
+    INSIDE the occupied and the virtual blocks and therefore never enter a denominator."""
+    inp = inputs.build(mol, bname, level, verbose=False)
+    kw = dict(log=None, conv_e=1e-10, conv_dm=1e-8)
+    r0 = scf.run_scf(inp, OracleBackend(inp, fn), fn, **kw)
+    be = OracleBackend(inp, fn)
+    be.occ_solver = scf.OccupiedRotation(inp.S, inp.nocc)
+    r1 = scf.run_scf(inp, be, fn, **kw)
+    # converged 100x tighter than the driver does: the last cycles move dm by 1e-9, where a 1e-10 difference in
+    # the occupied space decides a cycle earlier or later
+    assert r0["converged"] and r1["converged"] and abs(r1["cycles"] - r0["cycles"]) <= 3
+    assert r1["E_tot"] == pytest.approx(r0["E_tot"], abs=1e-9)
+    assert np.abs(r1["dm"] - r0["dm"]).max() < 1e-7
+    st = be.occ_solver.stats
+    assert st["rotated"] >= 2 * st["exact"] and st["exact"] >= 1
+    # at the driver's own thresholds (dft.py:243) the two loops stop in the same cycle (+-1)
+    d0 = scf.run_scf(inp, OracleBackend(inp, fn), fn, log=None)
+    be2 = OracleBackend(inp, fn); be2.occ_solver = scf.OccupiedRotation(inp.S, inp.nocc)
+    d1 = scf.run_scf(inp, be2, fn, log=None)
+    assert abs(d1["cycles"] - d0["cycles"]) <= 1 and d1["E_tot"] == pytest.approx(d0["E_tot"], abs=1e-7)
+    # the occupied orbitals it returns are S-orthonormal and the occupied energies are the exact ones
+    U = be.occ_solver.U.numpy()
+    assert np.abs(U.T @ inp.S @ U - np.eye(inp.S.shape[0])).max() < 1e-10
+    assert np.abs(r1["mo_energy"][:inp.nocc] - r0["mo_energy"][:inp.nocc]).max() < 1e-6
+
+
+def test_occupied_rotation_falls_back_when_the_fock_matrix_jumps():
+    rng = np.random.default_rng(3)
+    n, no = 30, 7
+    S = np.eye(n) + 0.05 * (lambda a: a + a.T)(rng.normal(size=(n, n))) / n
+    F0 = (lambda a: a + a.T)(rng.normal(size=(n, n)))
+    sol = scf.OccupiedRotation(S, no)
+    from scipy.linalg import eigh as _eigh
+    for F in (F0, F0 + 1e-3 * (lambda a: a + a.T)(rng.normal(size=(n, n))), (lambda a: a + a.T)(rng.normal(size=(n, n)))):
+        e, Co = sol.occupied(F)
+        e_ref, C_ref = _eigh(F, S)
+        P, P_ref = Co.numpy() @ Co.numpy().T, C_ref[:, :no] @ C_ref[:, :no].T
+        assert np.abs(P - P_ref).max() < 1e-8                  # same occupied projector every time
+    assert sol.stats["exact"] == 2 and sol.stats["rotated"] == 1   # first call and the jump: full solver
+
+
 def _drift_worker(rank, world, port, out_dir):
     """Two replicas of the host SCF loop under gloo; rank 1's LOCAL view of the device results is off by
     an ulp-scale perturbation every cycle (what different BLAS thread counts or different GPUs behind the
