@@ -58,9 +58,10 @@ def build(atom_path, basis_name="sto-3g", grid_level=3, device="cpu", verbose=Tr
         from .cholesky import cholesky_eri
         import time
         t0 = time.time()
-        chol = cholesky_eri(shells, tol=chol_tol)
+        chol = cholesky_eri(shells, tol=chol_tol, device=device)   # on a GPU: the factorisation's algebra and the vectors stay there
         if verbose:
-            print(f"Cholesky vectors of the ERI: {chol.shape[0]} (threshold {chol_tol:g}, {time.time() - t0:.1f} s on the host)")
+            where = "integral columns on the host, algebra and vectors on the device" if str(device).startswith("cuda") else "on the host"
+            print(f"Cholesky vectors of the ERI: {chol.shape[0]} (threshold {chol_tol:g}, {time.time() - t0:.1f} s; {where})")
     else:
         raise ValueError(f"eri_mode {eri_mode!r}: expected 'dense' or 'cholesky'")
     return SCFInputs(symbols, xyz, shells, grids, S, T, V, T + V, eri,

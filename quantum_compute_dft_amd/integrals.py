@@ -135,11 +135,15 @@ class EriColumns:
         _load().qc_eri_diag(self._h, d.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
         return d
 
-    def cols(self, C, D, screen=1e-14):
-        """(nfC*nfD, nao, nao): entry [k*nfD + l] is the symmetric matrix (..|kl)."""
+    def cols(self, C, D, screen=1e-14, out=None):
+        """(nfC*nfD, nao, nao): entry [k*nfD + l] is the symmetric matrix (..|kl).  `out`: a C-contiguous float64
+        buffer of nfC*nfD*nao^2 elements to write into (e.g. pinned memory), returned reshaped."""
         nf = (2 * int(self.shells.l[C]) + 1) * (2 * int(self.shells.l[D]) + 1)
-        out = np.empty((nf, self.nao, self.nao))
+        if out is None:
+            out = np.empty((nf, self.nao, self.nao))
+        else:
+            assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"] and out.size == nf * self.nao * self.nao
         rc = _load().qc_eri_cols(self._h, int(C), int(D), float(screen), out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
         if rc != 0:
             raise RuntimeError("qc_eri_cols failed (diag() must be called first)")
-        return out
+        return out.reshape(nf, self.nao, self.nao)

@@ -498,6 +498,27 @@ def test_factorised_jk_matches_dense_eri_oracle(dev, bname, tol):
     assert np.abs(d_K.cpu().numpy() - K_ref).max() <= bound
 
 
+def test_cholesky_with_the_algebra_on_the_device_matches_the_host_factorisation(dev):
+    """cholesky_eri(device=...): integral columns from the host engine, residual updates and rank-1 updates through
+    torch on the GPU, vectors left there.  As many vectors as the host factorisation (ties between the equal diagonal
+    elements (ij|ij) = (ji|ji) may be broken differently, so the vectors themselves need not coincide); both
+    reconstruct the ERI to the threshold."""
+    from quantum_compute_dft_amd import integrals
+    from quantum_compute_dft_amd.cholesky import cholesky_eri
+    syms, xyz = basis.parse_xyz("O 0 0 0.1173; H 0 0.7572 -0.4692; H 0 -0.7572 -0.4692")
+    sh = basis.build_shells(syms, xyz, "def2-svp")
+    tol = 1e-9
+    L_h = cholesky_eri(sh, tol=tol)
+    L_d = cholesky_eri(sh, tol=tol, device="cuda:0")
+    assert torch.is_tensor(L_d) and L_d.is_cuda and tuple(L_d.shape) == L_h.shape
+    n = sh.nao
+    eri = torch.as_tensor(integrals.int2e(sh).reshape(n * n, n * n), device=dev)
+    for L in (L_d, torch.as_tensor(L_h, device=dev)):
+        Lm = L.reshape(L.shape[0], n * n)
+        assert float((eri - Lm.T @ Lm).abs().max()) < tol
+        assert float((L - L.transpose(1, 2)).abs().max()) < 1e-12          # every vector symmetric
+
+
 @pytest.mark.parametrize("fn", ["LDA", "B3LYP"])
 def test_scf_with_factorised_jk_matches_dense_scf(dev, fn):
     from quantum_compute_dft_amd import inputs, scf
