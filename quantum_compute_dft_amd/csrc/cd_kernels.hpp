@@ -272,15 +272,30 @@ __global__ __launch_bounds__(256) void k_cd_vsum(int naux, int nB, const double 
 
 // part[y][e] = sum_{P in slice y} v[P] L[P][e]; slices of `pslice` vectors, summed afterwards
 __global__ __launch_bounds__(256) void k_cd_axpy(long n2, int naux, int pslice, const double *__restrict__ L,
-                                                 const double *__restrict__ v, double *__restrict__ part)
+                                                 const double *__restrict__ v, double *__restrict__ part, int n = 0)
 {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= n2) return;
     const int p0 = blockIdx.y * pslice, p1 = min(naux, p0 + pslice);
     double s = 0.0;
+    // every L_P is symmetric (include/dft_solver.h): only elements on or above the diagonal are read -- this second
+    // pass over the vectors moves half their bytes -- and k_sym_from_upper fills the rest of J afterwards
+    if (n > 0 && (int)(e % n) < (int)(e / n)) {
+        part[(size_t)blockIdx.y * n2 + e] = 0.0;
+        return;
+    }
 #pragma unroll 4
     for (int p = p0; p < p1; ++p) s += v[p] * L[(size_t)p * n2 + e];
     part[(size_t)blockIdx.y * n2 + e] = s;
+}
+
+// J[a][b] = J[b][a] for b < a (the axpy pass only produced the upper triangle)
+__global__ __launch_bounds__(256) void k_sym_from_upper(int n, double *__restrict__ J)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)n * n) return;
+    const int a = (int)(e / n), b = (int)(e % n);
+    if (b < a) J[e] = J[(size_t)b * n + a];
 }
 
 } // namespace qcdft

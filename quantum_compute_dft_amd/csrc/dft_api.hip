@@ -515,8 +515,9 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
         if (!reserve(s, s->jpart, sizeof(double) * (size_t)nsl * n2, "hipMalloc(cd J slabs)")) return -1;
         double *jp = (double *)s->jpart.p;
         if (fused_dot) hipLaunchKernelGGL(k_cd_vsum, dim3((unsigned)((naux + 255) / 256)), dim3(256), 0, st, naux, npair_h, vpart, v);
-        hipLaunchKernelGGL(k_cd_axpy, dim3((unsigned)eb, (unsigned)nsl), dim3(256), 0, st, n2, naux, pslice, L, v, jp);
+        hipLaunchKernelGGL(k_cd_axpy, dim3((unsigned)eb, (unsigned)nsl), dim3(256), 0, st, n2, naux, pslice, L, v, jp, nao);
         hipLaunchKernelGGL(k_sum_slabs8, dim3((unsigned)((n2 + 31) / 32)), dim3(256), 0, st, (size_t)n2, nsl, (size_t)n2, jp, J);
+        hipLaunchKernelGGL(k_sym_from_upper, dim3((unsigned)eb), dim3(256), 0, st, nao, J);
     }
     return hip_ok(s, hipGetLastError(), "factorised J/K launch") ? 0 : -1;
 }
