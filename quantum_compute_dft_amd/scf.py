@@ -134,11 +134,12 @@ class OccupiedRotation:
     cycle) when the first-order rotation exceeds 0.5, the fixed point has not reached `tol` in `max_inner` steps or
     grows, or the aufbau order is in doubt (highest occupied level within 1e-3 Ha of the lowest virtual diagonal).
 
-    Where it pays (profiles/r02_eigensolver.txt): the fixed point needs 15-20 steps in the middle of an SCF run (the
-    Fock matrix still moves by 1e-2) and 4-6 at its end, each a handful of small GEMMs.  On the device at n = 494
-    that is ~2 ms against 11.4 ms for hipSOLVER's syevd; at n = 114 / 246 on one host thread it is no faster than
-    dsyevd (0.65 / 3.2 ms), so `eigensolver="auto"` uses it only in the device-resident loop (from 400 functions).
-    Same converged energies to 1e-10 Ha and the same cycle counts as the exact loop (tests/test_scf_cpu.py)."""
+    Where it pays (profiles/r02_eigensolver.txt): solved to 1e-10 the fixed point needs 15-20 steps in the middle of
+    an SCF run (the Fock matrix still moves by 1e-2) and 4-6 at its end; stopped at 1e-3 x the last density change
+    (`accuracy`, inexact diagonalisation -- the orbitals stay exactly orthonormal) it needs 3-5 per cycle.  Per SCF
+    cycle of the real molecules: n = 494 (device) 15.0 against 23.4 ms, n = 246 (host) 5.9 against 6.9 ms, n = 114
+    (host) 1.18 against 1.21 ms -- `eigensolver="auto"` uses it from 200 functions.  Same converged energies (to the
+    SCF's own thresholds) and cycle counts within one of the exact loop (tests/test_scf_cpu.py)."""
 
     def __init__(self, S, nocc, device=None, tol=1e-10, max_inner=60):
         import torch
@@ -161,10 +162,14 @@ class OccupiedRotation:
         self.stats["exact"] += 1
         return e, self.U[:, :self.no]
 
-    def occupied(self, F):
+    def occupied(self, F, accuracy=None):
         """(orbital energies, C_occ (n, nocc)) for the Fock matrix F (numpy array or tensor on self.dev); the
-        energies are exact for the occupied block, diagonal estimates for the virtual one after a rotation."""
+        energies are exact for the occupied block, diagonal estimates for the virtual one after a rotation.
+        `accuracy`: residual at which the fixed point may stop in THIS call (never below self.tol); the SCF loop
+        passes 1e-3 x the last density change, so a cycle that still moves the density by 1e-3 is not solved to
+        1e-10 -- the returned orbitals are exactly orthonormal either way, i.e. always a valid trial density."""
         t, no = self.t, self.no
+        tol = self.tol if accuracy is None else min(max(self.tol, float(accuracy)), 1e-5)
         F = F if t.is_tensor(F) else t.as_tensor(F, dtype=t.float64, device=self.dev)
         if self.U is None or no == 0 or no == F.shape[0]:
             return self._exact(F)
@@ -184,7 +189,7 @@ class OccupiedRotation:
             self.stats["inner_steps"] += 1
             if it % every == 0:
                 r = float(R.abs().max())
-                if r < self.tol:
+                if r < tol:
                     ok = True
                     break
                 if not (r < 4.0 * prev):    # diverging (or NaN)
@@ -277,12 +282,13 @@ class HipBackend:
         if world > 1:
             self._sharded = ShardedFock(nao, self._local_sweep, self._local_jk, self.dev, group)
         # "exact": eigh(F, S) every cycle, the reference's loop (dft.py:227); "rotate": occupied-subspace rotation with
-        # the full solver as first cycle and fallback; "auto": rotate where it pays -- the device-resident loop
+        # the full solver as first cycle and fallback; "auto": rotate where it pays -- from 200 basis functions
+        # (n = 114: 1.18 against 1.21 ms per cycle, break-even; n = 246: 5.9 against 6.9; n = 494: 15.0 against 23.4)
         self.eigh = FockDiagonaliser(inp.S, self.dev, device_from=0 if self.device_resident else device_from)
         self.occ_solver = None
         if eigensolver not in ("auto", "rotate", "exact"):
             raise ValueError(f"eigensolver {eigensolver!r}: expected 'auto', 'rotate' or 'exact'")
-        if eigensolver == "rotate" or (eigensolver == "auto" and self.device_resident and nao >= device_from):
+        if eigensolver == "rotate" or (eigensolver == "auto" and nao >= 200):
             self.occ_solver = OccupiedRotation(inp.S, inp.nocc, self.dev if self.device_resident else None)
         torch.cuda.synchronize()
         self.init_time = time.time() - t0
@@ -399,9 +405,11 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     solve_full = getattr(backend, "eigh", None) or (lambda F: eigh(F, S))
     occ = getattr(backend, "occ_solver", None)
 
+    last_ddm = [None]
+
     def solve(F):   # (orbital energies, C_occ): the loop never uses the virtual orbitals (dft.py:182,228)
         if occ is not None:
-            e_, co_ = occ.occupied(F)
+            e_, co_ = occ.occupied(F, None if last_ddm[0] is None else 1e-3 * last_ddm[0])
             return e_.numpy(), co_.numpy()
         e_, C_ = solve_full(F)
         return e_, C_[:, :nocc]
@@ -441,6 +449,7 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         if sync:
             sync.broadcast_numpy([dm_new, cocc_new, scal])
         E_one, E_coul, E_ex, ddm = (float(x) for x in scal)
+        last_ddm[0] = ddm
         E_tot = E_one + E_coul + E_xc + E_ex + inp.E_nuc                               # dft.py:236
         dE = E_tot - E_old
         it_times.append(time.time() - t_it)
@@ -468,9 +477,11 @@ def _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     X = backend.eigh.X                                                                # S^-1/2 (FockDiagonaliser, once per S)
     sqrt2 = float(np.sqrt(2.0))
 
+    last_ddm = [None]
+
     def eigh_occ(F):                                                                   # dft.py:181,227 on the device
         if backend.occ_solver is not None:
-            e, co = backend.occ_solver.occupied(F)
+            e, co = backend.occ_solver.occupied(F, None if last_ddm[0] is None else 1e-3 * last_ddm[0])
             return e, co * sqrt2
         e, Cp = t.linalg.eigh(X.T @ F @ X)
         return e, (X @ Cp[:, :nocc]) * sqrt2
@@ -507,6 +518,7 @@ def _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         if sync:
             sync.broadcast([dm_new, cocc_new, scal])
         E_one, E_coul, E_ex, ddm = scal.tolist()                                       # the cycle's only download
+        last_ddm[0] = ddm
         E_tot = E_one + E_coul + E_xc + E_ex + inp.E_nuc
         dE = E_tot - E_old
         it_times.append(time.time() - t_it)

@@ -330,7 +330,7 @@ def test_device_resident_scf_matches_the_host_loop(dev, fn, eri_mode):
     kw = dict(log=None, conv_e=1e-11, conv_dm=1e-9)
     r_h = scf.run_scf(inp, scf.HipBackend(inp, fn, device_resident=False), fn, **kw)
     be = scf.HipBackend(inp, fn, device_resident=True)
-    assert be.device_resident and be.eigh.on_device and be.occ_solver is None   # "auto": rotation only from 400 functions
+    assert be.device_resident and be.eigh.on_device and be.occ_solver is None   # "auto": rotation only from 200 functions
     r_d = scf.run_scf(inp, be, fn, **kw)
     # the occupied-subspace rotation forced on, on the device: same loop again
     be_r = scf.HipBackend(inp, fn, device_resident=True, eigensolver="rotate")
