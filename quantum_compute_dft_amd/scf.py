@@ -150,6 +150,15 @@ class OccupiedRotation:
         self.U = None
         self.stats = {"exact": 0, "rotated": 0, "inner_steps": 0}
 
+    def _small_eigh(self, M):
+        """eigh of an n_occ x n_occ matrix: on the host (hipSOLVER needs ~1 ms for a 47 x 47 matrix, one LAPACK
+        thread 0.06 ms plus two 17 KB transfers)."""
+        t = self.t
+        if self.dev.type == "cpu":
+            return t.linalg.eigh(M)
+        w, V = np.linalg.eigh(M.cpu().numpy())
+        return t.as_tensor(w, device=self.dev), t.as_tensor(V, device=self.dev)
+
     def _exact(self, F):
         t = self.t
         Fp = self.X.T @ F @ self.X
@@ -198,7 +207,7 @@ class OccupiedRotation:
             K = K - R / den
         if not ok:
             return self._exact(F)
-        lam, V = t.linalg.eigh(K.T @ K)
+        lam, V = self._small_eigh(K.T @ K)
         lam = lam.clamp_min(0.0)
         Mo = (V / t.sqrt(1.0 + lam)) @ V.T                                    # (1 + K^T K)^-1/2
         g = t.where(lam > 1e-12, (1.0 / t.sqrt(1.0 + lam) - 1.0) / lam.clamp_min(1e-300), t.full_like(lam, -0.5))
@@ -208,7 +217,7 @@ class OccupiedRotation:
         Uv2 = T + ((T @ K) @ G) @ K.T
         Uo2 = (Uo + Uv @ K) @ Mo
         Aoo2 = Mo @ (Aoo + Aov @ K + K.T @ Avo + K.T @ (Avv @ K)) @ Mo        # occupied block in the rotated basis
-        eo, Vo = t.linalg.eigh(0.5 * (Aoo2 + Aoo2.T))
+        eo, Vo = self._small_eigh(0.5 * (Aoo2 + Aoo2.T))
         if float(eo[-1]) > float(dv.min()) - 1e-3:                            # aufbau order in doubt
             return self._exact(F)
         Uo2 = Uo2 @ Vo                                                        # canonical occupied orbitals
@@ -496,6 +505,8 @@ def _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     res = {"converged": False}
     want_k = functional == "B3LYP"
     scal = t.zeros(4, dtype=f64, device=dev)
+    import os
+    prof = [] if os.environ.get("QCDFT_SCF_PROFILE") else None      # per-part times of the host-side-of-the-cycle (adds syncs)
     for cycle in range(max_cycle):
         t_it = time.time()
         backend.d_dm.copy_(dm); backend.d_cocc.copy_(cocc)                             # device to device
@@ -504,15 +515,23 @@ def _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         xc_times.append(t_xc); jk_times.append(time.time() - t_it - t_xc)
         J, K, V = backend.d_J, backend.d_K, backend.d_v
         if root or sync is None:
+            tp = [time.time()]
+            mark = (lambda: (t.cuda.synchronize(), tp.append(time.time()))) if prof is not None else (lambda: None)
             F = H + J + 0.5 * (V + V.T)                                                # dft.py:212,223
             if want_k:
                 F = F - (0.5 * c_hf) * K                                               # dft.py:221
+            mark()
             F = diis.update(S, dm, F, keep_on_device=True)
+            mark()
             e, cocc_new = eigh_occ(F)
+            mark()
             dm_new = cocc_new @ cocc_new.T
             scal = t.stack([(dm_new * H).sum(), 0.5 * (dm_new * J).sum(),
                             (-0.25 * c_hf) * (dm_new * K).sum() if want_k else t.zeros((), dtype=f64, device=dev),
                             t.linalg.norm(dm_new - dm)])
+            mark()
+            if prof is not None and len(tp) == 5:
+                prof.append([1e3 * (b - a) for a, b in zip(tp, tp[1:])])
         else:
             dm_new, cocc_new = t.empty_like(dm), t.empty_like(cocc)
         if sync:
@@ -532,4 +551,9 @@ def _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         dm, cocc, E_old = dm_new, cocc_new, E_tot
     res["dm"] = dm.cpu().numpy()
     res["mo_energy"] = e.cpu().numpy()
+    if prof:
+        med = np.median(np.array(prof[1:] if len(prof) > 1 else prof), axis=0)
+        res["device_parts_ms"] = dict(zip(("fock", "diis", "eigen", "density_energies"), (float(x) for x in med)))
+        if log:
+            log("device-resident parts (median ms per cycle): " + ", ".join(f"{k} {v:.3f}" for k, v in res["device_parts_ms"].items()))
     return _finish(res, t_start, xc_times, jk_times, it_times)
