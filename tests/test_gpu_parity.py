@@ -102,6 +102,31 @@ def test_alternative_kernel_paths_match_oracle(dev, xc_type, path):
         _check(exc, v, exc_ref, v_ref)
 
 
+@pytest.mark.parametrize("xc_type", [0, 1, 2])
+def test_sixteen_wave_kernels_match_oracle(dev, xc_type):
+    """Option ws_waves = 16: the 8 MFMA + 8 loader wave form of the nao <= 128 kernels (csrc/xc_ws16_kernels.hpp),
+    every tile count NT = 1..8, ragged grids, both walking orders."""
+    for ngrid, nao in ((7, 3), (1025, 17), (3001, 36), (1531, 65), (2500, 114), (1300, 128), (999, 90)):
+        dm, ao, gr, w = synth_inputs(ngrid, nao, seed=900 + ngrid + nao)
+        exc_ref, v_ref = oracle.compute_xc(xc_type, dm, ao, w, gr)
+        for order in (0, 3):
+            exc, v = _run(_solver(xc_type, ws_waves=16, sweep_order=order), dm, ao, gr if xc_type else None, w, dev)
+            _check(exc, v, exc_ref, v_ref)
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3])
+def test_walking_order_of_the_contraction_kernels_does_not_change_results_beyond_roundoff(dev, order):
+    """sweep_order bit 0 / 1: the density / Vxc kernel walks the grid from its end (Infinity-Cache reuse between the
+    two passes).  rho is computed per point, so Exc is bit-identical; Vxc sums its sub-tiles in another order."""
+    dm, ao, gr, w = synth_inputs(20011, 114, seed=61)
+    base = _run(_solver(1, sweep_order=2), dm, ao, gr, w, dev)
+    got = _run(_solver(1, sweep_order=order), dm, ao, gr, w, dev)
+    assert got[0] == base[0]
+    assert np.abs(got[1] - base[1]).max() <= 1e-13 * np.abs(base[1]).max()
+    exc_ref, v_ref = oracle.compute_xc(1, dm, ao, w, gr, omp=True)
+    _check(got[0], got[1], exc_ref, v_ref)
+
+
 @pytest.mark.parametrize("opt,val", [("rho_rows", 128), ("rho_rows", 64), ("ksplit", 3)])
 def test_large_basis_kernel_options_match_oracle(dev, opt, val):
     """nao > 128 takes the tiled kernels: both density tilings (64-row two-per-CU, 128-row) and a forced

@@ -28,6 +28,8 @@ while time.time() < t_end:
         e_ref, v_ref = oracle.compute_xc(xc, dm, ao, w, gr if xc else None, quirks=bool(quirks))
         s = q.DFTSolverWrapper(q.library_path(), names[xc]); s.set_option("path", path); s.set_option("quirks", quirks)
         if rng.random() < 0.5: s.set_option("rho_rows", 128)
+        if rng.random() < 0.3: s.set_option("ws_waves", 16)
+        s.set_option("sweep_order", int(rng.integers(0, 4)))
         d_v = torch.full((nao, nao), 3.0, dtype=torch.float64, device=dev)
         e = s.compute_xc(ngrid, nao, t(dm), t(ao), t(w), d_v, t(gr) if xc else None)
         ee = abs(e - e_ref) / max(1e-300, abs(e_ref)) if e_ref else abs(e)
