@@ -17,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _rank_main(rank, world, port, fn, eri_mode, out_dir, device_resident=False):
+def _rank_main(rank, world, port, fn, eri_mode, out_dir, device_resident=False, eigensolver="auto"):
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from quantum_compute_dft_amd import inputs, scf
@@ -25,7 +25,7 @@ def _rank_main(rank, world, port, fn, eri_mode, out_dir, device_resident=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         inp = inputs.build("H2O", "def2-svp", 3, verbose=False, eri_mode=eri_mode, chol_tol=1e-10)
-        be = scf.HipBackend(inp, fn, rank=rank, world=world, device="cuda:0", device_resident=device_resident)
+        be = scf.HipBackend(inp, fn, rank=rank, world=world, device="cuda:0", device_resident=device_resident, eigensolver=eigensolver)
         res = scf.run_scf(inp, be, fn, log=None, conv_e=1e-11, conv_dm=1e-9)
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), e=res["E_tot"], exc=res["E_xc"], ex=res["E_ex_hf"],
                  dm=res["dm"], conv=res["converged"], ngrid=be.ngrid)
@@ -33,15 +33,16 @@ def _rank_main(rank, world, port, fn, eri_mode, out_dir, device_resident=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fn,eri_mode,device_resident", [("B3LYP", "cholesky", False), ("GGA", "dense", False),
-                                                         ("B3LYP", "dense", False), ("B3LYP", "cholesky", True)])
-def test_two_ranks_on_one_gpu_match_the_single_rank_scf(tmp_path, fn, eri_mode, device_resident):
+@pytest.mark.parametrize("fn,eri_mode,device_resident,eigensolver", [
+    ("B3LYP", "cholesky", False, "auto"), ("GGA", "dense", False, "auto"), ("B3LYP", "dense", False, "auto"),
+    ("B3LYP", "cholesky", True, "auto"), ("GGA", "cholesky", True, "rotate"), ("B3LYP", "dense", False, "rotate")])
+def test_two_ranks_on_one_gpu_match_the_single_rank_scf(tmp_path, fn, eri_mode, device_resident, eigensolver):
     import torch.multiprocessing as mp
     from quantum_compute_dft_amd import inputs, scf
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no HIP device is visible")
     world = 2
-    mp.spawn(_rank_main, args=(world, _free_port(), fn, eri_mode, str(tmp_path), device_resident), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(world, _free_port(), fn, eri_mode, str(tmp_path), device_resident, eigensolver), nprocs=world, join=True)
     inp = inputs.build("H2O", "def2-svp", 3, verbose=False, eri_mode=eri_mode, chol_tol=1e-10)
     ref = scf.run_scf(inp, scf.HipBackend(inp, fn), fn, log=None, conv_e=1e-11, conv_dm=1e-9)
     r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
