@@ -354,6 +354,82 @@ def strong_leg(lib_path, dev, dist, backend, world, rank, workload, steps=6, war
             "hbm_frac": b_alg / med[2] / 1e9 / HBM_PEAK_GBS, "mfma_frac": f_alg / med[2] / 1e12 / F64_MFMA_PEAK_TF}
 
 
+def scf_sharded_leg(lib_path, dev, dist, backend, world, rank, workload="anthracene_b3lyp_def2tzvp", cycles=6, warmup=2):
+    """One SCF cycle of the Anthracene B3LYP/def2-TZVP shape with the device work sharded over the ranks the way
+    scf.HipBackend does it under torch.distributed: rank r keeps grid block shard_bounds(ngrid, N, r) and Cholesky
+    vectors vector_bounds(naux, N, r) resident; per cycle local J/K + local XC sweep, ONE all-reduce of
+    [Vxc | J | K | Exc] (3 nao^2 + 1 doubles), then rank 0 alone builds F, solves the eigenproblem (hipSOLVER syevd:
+    a synthetic Fock sequence says nothing about the rotation solver) and forms dm, and ONE broadcast of [dm | cocc]
+    brings the replicas back in step.  Synthetic planes and vectors (6 nao of them), device-resident."""
+    from quantum_compute_dft_amd.grid_shard import shard_bounds, vector_bounds
+    f64 = torch.float64
+    xc, nao, ngrid = WORKLOADS[workload]
+    n2, nocc = nao * nao, 47
+    naux = 6 * nao
+    lo, hi = shard_bounds(ngrid, world, rank)
+    plo, phi = vector_bounds(naux, world, rank)
+    n_loc, nv_loc = hi - lo, phi - plo
+    dm, ao, gr, w = synth(max(n_loc, 16), nao, True, dev, SEED + 104729 * (rank + 1))
+    g = torch.Generator(device=dev); g.manual_seed(SEED + 31 * (rank + 1))
+    chol = torch.randn((max(nv_loc, 1), nao, nao), dtype=f64, device=dev, generator=g) * 1e-2
+    solver = q.DFTSolverWrapper(lib_path, xc)
+    buf = torch.zeros(3 * n2 + 1, dtype=f64, device=dev)                            # [Vxc | J | K | Exc]
+    d_v, d_J, d_K = (buf[k * n2:(k + 1) * n2].view(nao, nao) for k in range(3))
+    d_e = buf[3 * n2:]
+    state = torch.zeros(n2 + nao * nocc, dtype=f64, device=dev)                     # [dm | cocc]
+    d_dm, d_c = state[:n2].view(nao, nao), state[n2:].view(nao, nocc)
+    C = torch.linalg.qr(torch.randn((nao, nocc), dtype=f64, device=dev, generator=g))[0]
+    d_c.copy_(C * float(np.sqrt(2.0))); d_dm.copy_(d_c @ d_c.T)
+    H = torch.diag(torch.linspace(-1.0, 1.0, nao, dtype=f64, device=dev))
+
+    def coll(fn, t):
+        if world == 1:
+            return
+        if backend == "nccl":
+            fn(t)
+        else:
+            h = t.cpu(); fn(h); t.copy_(h)
+
+    coll(lambda t: dist.broadcast(t, 0), state)
+    rows = []
+    for it in range(warmup + cycles):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        if nv_loc:
+            solver.compute_jk_factorized(nao, nv_loc, nocc, chol, d_dm, d_c, d_J, d_K)
+        else:
+            d_J.zero_(); d_K.zero_()
+        if n_loc:
+            solver.compute_xc_async(n_loc, nao, d_dm, ao, w, d_v, d_e, gr)
+        else:
+            d_v.zero_(); d_e.zero_()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        coll(lambda t: dist.all_reduce(t), buf)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        if rank == 0:
+            F = H + 1e-3 * (d_J + 0.5 * (d_v + d_v.T) - 0.1 * d_K)
+            e, Cf = torch.linalg.eigh(F)
+            d_c.copy_(Cf[:, :nocc] * float(np.sqrt(2.0))); d_dm.copy_(d_c @ d_c.T)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        coll(lambda t: dist.broadcast(t, 0), state)
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+        if it >= warmup:
+            rows.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0))
+    t = torch.tensor(rows, dtype=f64, device=dev if backend == "nccl" else "cpu")
+    own = (1e3 * t.median(dim=0).values).tolist()       # this rank's parts (rank 0's are reported: a waiting rank books its wait as "broadcast")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    med = (1e3 * t.median(dim=0).values).tolist()
+    del ao, gr, w, chol, solver
+    torch.cuda.empty_cache()
+    return {"workload": f"{workload} shape: nao {nao}, {ngrid} grid points and {naux} synthetic Cholesky vectors sharded over {world} GPU(s)",
+            "scaling": "strong", "ms_per_cycle": med[4], "slowest_rank_device_jk_xc_ms": med[0],
+            "parts_ms_rank0": {"device_jk_xc": own[0], "allreduce": own[1], "fock_eigh_density": own[2], "broadcast": own[3]},
+            "allreduce_payload_bytes": 8 * (3 * n2 + 1), "broadcast_payload_bytes": 8 * (n2 + nao * nocc),
+            "statistic": f"median over {cycles} cycles of the max over ranks"}
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a torch.distributed.run child
     (fresh processes; this one has not touched the GPU and never does) and leave with its exit code."""
@@ -491,12 +567,13 @@ def main():
         solver.set_option("profile", 0)
         kern = {k: float(np.mean(v)) for k, v in acc.items()}
 
-    strong5 = None
+    strong5 = scf_sh = None
     if not strong and not args.no_extra_legs:            # every rank takes part (collective inside)
         del ao, gr
         ao = gr = None
         torch.cuda.empty_cache()
         strong5 = strong_leg(lib_path, dev, dist, args.backend, world, rank, "c33_b3lyp_def2svp")
+        scf_sh = scf_sharded_leg(lib_path, dev, dist, args.backend, world, rank) if world > 1 else None
         if rank == 0 and world == 1:
             dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)   # the same inputs again for the legs below
 
@@ -536,6 +613,8 @@ def main():
         }
         if strong5 is not None:
             line["strong_config5"] = strong5
+            if scf_sh is not None:
+                line["scf_iteration_anthracene_sharded"] = scf_sh
         if world == 1 and not strong and not args.no_extra_legs:
             line["ao_sweep"] = ao_sweep_leg(lib_path, dev)
             line["scf_iteration"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev)
