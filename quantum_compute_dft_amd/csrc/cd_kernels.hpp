@@ -31,10 +31,9 @@ constexpr int CD_BN = 256, CD_BK = 16, CD_LDB = CD_BN + 16; // 272 = 16 (mod 32)
 //   split = false: pair = b % npair, batch = b / npair, one chunk covering [0, G)
 // Rows of A/B past the chunk end read as zeros (descriptor range), columns past M/N only feed
 // discarded outputs.
-// DOT (half transform only, split = false): the B tiles are the Cholesky vectors themselves, so the
-// workgroups of a-block 0 also accumulate sum B[g][b] * Dm[g][b] over their tile while it passes
-// through registers and leave one partial of v_P = L_P : D per (P, b-block) in vpart -- the first of
-// J's two passes over L rides along for free.
+// DOT (half transform only, split = false): v_P = L_P : D is needed for J; with D = Cocc Cocc^T it equals
+// sum_{i,b} Yt_P[i][b] Cocc[b][i], a dot of each RESULT tile with a block of the A operand, taken at the epilogue:
+// one partial per (P, tile) in vpart -- the first of J's two passes over L costs no extra memory traffic.
 //
 // NW = waves per workgroup.  8: the tiles above, one workgroup per CU (LDS 90-106 KB).  4 (WGM = 1
 // only): tile 64 x 128, 57 KB, TWO workgroups per CU whose prologues, barriers and epilogues
@@ -54,7 +53,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && BK_ == 8) ? 3 : 2) void k_gemm
                                                            long chunk, int nB, int npair, int split,
                                                            double *__restrict__ C, int ldc, long strideC_batch,
                                                            long strideC_chunk,
-                                                           const double *__restrict__ Dm = nullptr,
                                                            double *__restrict__ vpart = nullptr,
                                                            int skip_lower = 0)
 {

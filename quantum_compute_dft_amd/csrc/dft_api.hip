@@ -439,8 +439,8 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
     // half transform: 64 x 256 tiles (8-row stages, four waves) while one 64-row tile holds all occupied orbitals,
     // 128 x 256 above; one partial of v_P per tile
     const int nBh = nB, npair_h = ((nocc + (nocc <= 64 ? 63 : 127)) / (nocc <= 64 ? 64 : 128)) * nBh;
-    // v_P = L_P : D.  With K wanted too, the half transform reads every L_P anyway and leaves the
-    // partial dots of its tiles (one per 256-column block); otherwise a pass of its own.
+    // v_P = L_P : D.  With K wanted too, the half transform leaves it as the dot of its result Yt_P with Cocc
+    // (D = Cocc Cocc^T is the entry point's contract), one partial per tile; otherwise a pass of its own over L with D.
     const bool fused_dot = J && K;
     if (J) {
         if (!reserve(s, s->cdv, sizeof(double) * (size_t)naux * (1 + npair_h), "hipMalloc(cd v)")) return -1;
@@ -471,14 +471,14 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
         double *cp = (double *)s->cdc.p, *yt = (double *)s->cdy.p, *kp = (double *)s->kpart.p;
         if (fresh && ldy != nao) // the pad column is read (into discarded outputs) but never written
             if (!hip_ok(s, hipMemsetAsync(yt, 0, s->cdy.cap, st), "memset(cd Yt)")) return -1;
-        const bool vecL = (nao % 2 == 0) && (((uintptr_t)L & 15) == 0) && (!fused_dot || ((uintptr_t)dm & 15) == 0);
+        const bool vecL = (nao % 2 == 0) && (((uintptr_t)L & 15) == 0);
         {
             ScopedTimer t(s, "cd_half");
             hipLaunchKernelGGL(k_pack_cocc, dim3((unsigned)(((long)nao * ldp + 255) / 256)), dim3(256), 0, st, nao, nocc, ldp, cocc, cp);
             // Yt_P (nocc x nao) = Cp^T L_P for every P
 #define QCDFT_HALF3(WGM, MI, VL, DOT, NW)                                                                             \
     hipLaunchKernelGGL((k_gemm_tn<WGM, MI, true, VL, DOT, NW, (WGM == 1 ? 8 : 0), (WGM == 1 ? 4 : 0)>), g, dim3(64 * NW), 0, st, (long)nao, nocc, nao, ldp, nao, \
-                       cp, 0L, L, n2, (long)nao, nBh, npair, 0, yt, ldy, (long)nocc * ldy, 0L, dm, vpart)
+                       cp, 0L, L, n2, (long)nao, nBh, npair, 0, yt, ldy, (long)nocc * ldy, 0L, vpart)
 #define QCDFT_HALF(WGM, MI, NW)                                                                                       \
     do {                                                                                                              \
         const int nA = (nocc + 64 * WGM - 1) / (64 * WGM), npair = nA * nBh;                                          \
@@ -499,7 +499,7 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
             // K = Yt^T Yt, split over the (P, i) rows
             dim3 g((unsigned)(nslab * live2));
             hipLaunchKernelGGL((k_gemm_tn<2, 4, true, true>), g, dim3(BG_THREADS), 0, st, G, nao, nao, ldy, ldy,
-                               yt, 0L, yt, 0L, chunk, nB, live2, 1, kp, nao, 0L, n2, (const double *)nullptr, (double *)nullptr, 1);
+                               yt, 0L, yt, 0L, chunk, nB, live2, 1, kp, nao, 0L, n2, (double *)nullptr, 1);
             hipLaunchKernelGGL(k_sum_slabs8, dim3((unsigned)((n2 + 31) / 32)), dim3(256), 0, st, (size_t)n2, nslab, (size_t)n2, kp, K);
             if (live2 < npair2)
                 hipLaunchKernelGGL(k_mirror_lower, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, nao, K);

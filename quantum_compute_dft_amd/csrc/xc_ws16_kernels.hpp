@@ -22,7 +22,6 @@
 namespace qcdft {
 
 constexpr int W16_THREADS = 1024; // 8 MFMA waves + 8 loader waves
-constexpr int W16_LOADERS = 512;
 
 template <int NT> struct W16Cfg {
     static constexpr int NCOL = 16 * NT;                      // padded AO columns
