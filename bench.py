@@ -21,7 +21,8 @@ Output = ONE JSON line on rank 0 (metric grid-points/s).  `roofline` is the WHOL
          events on the solver's stream); `cpu_baseline` is the prebuilt OpenMP CPU oracle timed on a
          bounded slice of the same inputs (N=1, rank 0 only); `ao_sweep` the AO-on-grid kernel on
          Benzene/def2-SVP's real shells and level-3 grid; `scf_iteration*` one SCF cycle at the Benzene
-         GGA and Anthracene B3LYP shapes; `k_build` the factorised exact exchange on the fp64 matrix cores.
+         GGA and Anthracene B3LYP shapes (synthetic operands, eigh(F, S) every cycle as the reference's loop);
+         `scf_benzene_real` the driver's whole SCF on the real Benzene PBE/def2-SVP (energy as checksum); `k_build` the factorised exact exchange on the fp64 matrix cores.
 """
 import argparse
 import glob
@@ -302,6 +303,35 @@ def ao_sweep_leg(lib_path, dev, reps=6, burst=10):
             "chained_ao_rho_vxc": {"ms_per_step": 1e3 * t_chain, "grid_points_per_sec": ngrid / t_chain,
                                    "exc": exc, "integral_rho": nelec,
                                    "note": "DFT_EvalAO + DFT_ComputeXC(GGA) per step on the real AO values, synthetic PSD density matrix"}}
+
+
+def scf_real_leg(lib_path, dev, molecule="Benzene", functional="GGA", basis_name="def2-svp"):
+    """The BASELINE metric "ms/SCF-iter (Benzene GGA)" on the REAL molecule: the driver's own loop (scf.run_scf, the
+    reference's thresholds |dE| < 1e-8, |d dm| < 1e-6, dft.py:243) on Benzene PBE/def2-SVP -- real shells, integrals,
+    level-3 grid -- once with the dense ERI (the reference's formulation, dft.py:166,203) and once with the
+    factorised J (Cholesky, 1e-8); eigensolver "auto" (occupied-subspace rotation at this size) and eigh(F, S) every
+    cycle (dft.py:227) side by side.  The converged energy is the checksum (rounds 1 and 2: -231.77070180 Ha)."""
+    import dataclasses
+    from quantum_compute_dft_amd import inputs, scf
+    from quantum_compute_dft_amd.cholesky import cholesky_eri
+    t0 = time.perf_counter()
+    inp = inputs.build(molecule, basis_name, 3, device=dev, verbose=False, eri_mode="dense")
+    t_build = time.perf_counter() - t0
+    inp_cd = dataclasses.replace(inp, eri=None, chol=cholesky_eri(inp.shells, tol=1e-8, device=dev))
+    out = {"workload": f"{molecule} {functional}/{basis_name}: nao {inp.shells.nao}, {inp.grids.size} grid points, {inp.nocc} occupied; real shells, "
+                       f"integrals and level-3 grid (host build {t_build:.1f} s, not timed)",
+           "statistic": "median per cycle after the first; thresholds of dft.py:243"}
+    for name, ii in (("dense_eri", inp), ("factorised_j", inp_cd)):
+        for eig in ("auto", "exact"):
+            be = scf.HipBackend(ii, functional, lib_path, device=dev, eigensolver=eig)
+            r = scf.run_scf(ii, be, functional, log=None)
+            out[f"{name}_{eig}"] = {"ms_per_cycle": r["iter_ms"], "xc_ms": r["xc_ms"], "jk_ms": r["jk_ms"], "cycles": r["cycles"],
+                                    "converged": bool(r["converged"]), "E_tot": r["E_tot"], "total_ms": 1e3 * r["total_time"],
+                                    "eigensolver": dict(be.occ_solver.stats) if be.occ_solver is not None else "eigh(F, S) every cycle"}
+            del be
+    del inp, inp_cd
+    torch.cuda.empty_cache()
+    return out
 
 
 def strong_leg(lib_path, dev, dist, backend, world, rank, workload, steps=6, warmup=2):
@@ -619,6 +649,7 @@ def main():
             line["ao_sweep"] = ao_sweep_leg(lib_path, dev)
             line["scf_iteration"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev)
             line["scf_iteration_factorised_j"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, eri="cholesky")
+            line["scf_benzene_real"] = scf_real_leg(lib_path, dev)
             del ao, gr
             torch.cuda.empty_cache()
             xa, na, ga = WORKLOADS["anthracene_b3lyp_def2tzvp"]

@@ -25,7 +25,7 @@ def main(argv=None):
     p.add_argument("--chol-tol", type=float, default=1e-9)
     p.add_argument("--eigensolver", default="auto", choices=["auto", "rotate", "exact"],
                    help="exact: eigh(F, S) every cycle as dft.py:227; rotate: occupied-subspace rotation from the previous cycle's "
-                        "orbitals, full solver as first cycle and fallback; auto (default): rotate from 200 basis functions, exact below")
+                        "orbitals, full solver as first cycle and fallback; auto (default): rotate from 80 basis functions, exact below")
     p.add_argument("--device-resident", type=int, default=-1,
                    help="1: Fock build, DIIS, eigh and the density stay in HBM (only scalars cross PCIe per cycle); "
                         "0: host loop (one pinned transfer each way per cycle); -1 (default): device from 200 basis functions")

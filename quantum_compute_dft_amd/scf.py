@@ -140,8 +140,9 @@ class OccupiedRotation:
     Where it pays (profiles/r02_eigensolver.txt): solved to 1e-10 the fixed point needs 15-20 steps in the middle of
     an SCF run (the Fock matrix still moves by 1e-2) and 4-6 at its end; stopped at 1e-3 x the last density change
     (`accuracy`, inexact diagonalisation -- the orbitals stay exactly orthonormal) it needs 3-5 per cycle.  Per SCF
-    cycle of the real molecules: n = 494 (device) 15.0 against 23.4 ms, n = 246 (host) 5.9 against 6.9 ms, n = 114
-    (host) 1.18 against 1.21 ms -- `eigensolver="auto"` uses it from 200 functions.  Same converged energies (to the
+    cycle of the real molecules: n = 494 (device) 12.5 against 23.4 ms, n = 246 (device) 4.3 against 6.9 ms, n = 114
+    (host, plain numpy: ~25 small BLAS/LAPACK calls) 0.86 against 1.23 ms; below ~80 functions dsyevd itself is
+    cheaper than those calls -- `eigensolver="auto"` uses it from 80 functions.  Same converged energies (to the
     SCF's own thresholds) and cycle counts within one of the exact loop (tests/test_scf_cpu.py)."""
 
     def __init__(self, S, nocc, device=None, tol=1e-10, max_inner=60):
@@ -149,7 +150,8 @@ class OccupiedRotation:
         self.t, self.no, self.tol, self.max_inner = torch, int(nocc), tol, max_inner
         self.dev = torch.device(device) if device is not None else torch.device("cpu")
         s, V = np.linalg.eigh(S)
-        self.X = torch.as_tensor(V / np.sqrt(s), dtype=torch.float64, device=self.dev)   # S^-1/2 (columns)
+        self.host = self.dev.type == "cpu"      # host form: plain numpy (a torch-CPU operation costs 3-5 us, ~70 of them per cycle)
+        self.X = V / np.sqrt(s) if self.host else torch.as_tensor(V / np.sqrt(s), dtype=torch.float64, device=self.dev)   # S^-1/2 (columns)
         self.U = None
         self.stats = {"exact": 0, "rotated": 0, "inner_steps": 0}
 
@@ -165,7 +167,12 @@ class OccupiedRotation:
     def _exact(self, F):
         t = self.t
         Fp = self.X.T @ F @ self.X
-        if self.dev.type == "cpu" or F.shape[0] < 400:
+        if self.host:
+            e, Cp = eigh(Fp, driver="evd")
+            self.U = self.X @ Cp
+            self.stats["exact"] += 1
+            return e, self.U[:, :self.no]
+        if F.shape[0] < 400:
             # one LAPACK thread beats hipSOLVER below ~400 functions (FockDiagonaliser: n = 246 2.5 against ~6 ms), also
             # from the device-resident loop: the few full solves of a run cross PCIe (2 n^2 doubles), the rotations do not
             e, Cp = eigh(Fp.cpu().numpy(), driver="evd")
@@ -184,6 +191,8 @@ class OccupiedRotation:
         1e-10 -- the returned orbitals are exactly orthonormal either way, i.e. always a valid trial density."""
         t, no = self.t, self.no
         tol = self.tol if accuracy is None else min(max(self.tol, float(accuracy)), 1e-5)
+        if self.host:
+            return self._occupied_host(np.asarray(F), tol)
         F = F if t.is_tensor(F) else t.as_tensor(F, dtype=t.float64, device=self.dev)
         if self.U is None or no == 0 or no == F.shape[0]:
             return self._exact(F)
@@ -229,6 +238,57 @@ class OccupiedRotation:
         self.U = t.cat([Uo2, Uv2], dim=1)
         self.stats["rotated"] += 1
         return t.cat([eo, dv]), Uo2
+
+
+    def _occupied_host(self, F, tol):
+        """The same algorithm in numpy (returns numpy arrays): at n = 114 one cycle is ~25 small BLAS/LAPACK calls."""
+        no = self.no
+        if self.U is None or no == 0 or no == F.shape[0]:
+            return self._exact(F)
+        U = self.U
+        A = U.T @ (F @ U)
+        d = np.diagonal(A)
+        do, dv = d[:no], d[no:]
+        Aoo, Aov, Avo, Avv = A[:no, :no], A[:no, no:], A[no:, :no], A[no:, no:]
+        rden = 1.0 / (dv[:, None] - do[None, :])
+        K = -Avo * rden
+        if not (np.abs(K).max() <= 0.5):
+            return self._exact(F)
+        prev, ok = float("inf"), False
+        for it in range(self.max_inner):
+            R = Avo + Avv @ K - K @ (Aoo + Aov @ K)
+            self.stats["inner_steps"] += 1
+            r = np.abs(R).max()
+            if r < tol:
+                ok = True
+                break
+            if not (r < 4.0 * prev):        # diverging (or NaN)
+                break
+            prev = min(prev, r)
+            K = K - R * rden
+        if not ok:
+            return self._exact(F)
+        lam, V = np.linalg.eigh(K.T @ K)
+        lam = np.maximum(lam, 0.0)
+        isq = 1.0 / np.sqrt(1.0 + lam)
+        Mo = (V * isq) @ V.T                                                  # (1 + K^T K)^-1/2
+        g = np.where(lam > 1e-12, (isq - 1.0) / np.maximum(lam, 1e-300), -0.5)
+        G = (V * g) @ V.T                                                     # (1 + K K^T)^-1/2 = 1 + K G K^T
+        Uo, Uv = U[:, :no], U[:, no:]
+        T = Uv - Uo @ K.T
+        Uv2 = T + ((T @ K) @ G) @ K.T
+        Uo2 = (Uo + Uv @ K) @ Mo
+        AvvK = Avv @ K
+        Aoo2 = Mo @ (Aoo + Aov @ K + K.T @ Avo + K.T @ AvvK) @ Mo             # occupied block in the rotated basis
+        eo, Vo = np.linalg.eigh(0.5 * (Aoo2 + Aoo2.T))
+        if eo[-1] > dv.min() - 1e-3:                                          # aufbau order in doubt
+            return self._exact(F)
+        Un = np.empty_like(U)
+        Un[:, :no] = Uo2 @ Vo                                                 # canonical occupied orbitals
+        Un[:, no:] = Uv2
+        self.U = Un
+        self.stats["rotated"] += 1
+        return np.concatenate([eo, dv]), Un[:, :no]
 
 
 class HipBackend:
@@ -296,14 +356,15 @@ class HipBackend:
         if world > 1:
             self._sharded = ShardedFock(nao, self._local_sweep, self._local_jk, self.dev, group)
         # "exact": eigh(F, S) every cycle, the reference's loop (dft.py:227); "rotate": occupied-subspace rotation with
-        # the full solver as first cycle and fallback; "auto": rotate where it pays -- from 200 basis functions
-        # (n = 114: 1.18 against 1.21 ms per cycle, break-even; n = 246: 5.9 against 6.9; n = 494: 15.0 against 23.4)
+        # the full solver as first cycle and fallback; "auto": rotate where it pays -- from 80 basis functions (per
+        # cycle of the real molecules: n = 24 0.23 against 0.21 ms and n = 36 0.37 against 0.34, so not there;
+        # n = 114 0.86 against 1.23; n = 246 4.3 against 6.9; n = 494 12.5 against 23.4)
         # the full solver: hipSOLVER from 400 functions whatever the loop form; the device loop needs X in HBM always
         self.eigh = FockDiagonaliser(inp.S, self.dev, device_from=0 if self.device_resident else 400)
         self.occ_solver = None
         if eigensolver not in ("auto", "rotate", "exact"):
             raise ValueError(f"eigensolver {eigensolver!r}: expected 'auto', 'rotate' or 'exact'")
-        if eigensolver == "rotate" or (eigensolver == "auto" and nao >= 200):
+        if eigensolver == "rotate" or (eigensolver == "auto" and nao >= 80):
             self.occ_solver = OccupiedRotation(inp.S, inp.nocc, self.dev if self.device_resident else None)
         if self.device_resident or self.diis_device is not None or self.eigh.on_device:
             # rocBLAS / hipSOLVER load their code objects and create their handles on first use (~0.1-0.3 s in all):
@@ -437,7 +498,7 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     def solve(F):   # (orbital energies, C_occ): the loop never uses the virtual orbitals (dft.py:182,228)
         if occ is not None:
             e_, co_ = occ.occupied(F, None if last_ddm[0] is None else 1e-3 * last_ddm[0])
-            return e_.numpy(), co_.numpy()
+            return np.asarray(e_), np.asarray(co_)
         e_, C_ = solve_full(F)
         return e_, C_[:, :nocc]
 

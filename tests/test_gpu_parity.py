@@ -355,7 +355,7 @@ def test_device_resident_scf_matches_the_host_loop(dev, fn, eri_mode):
     kw = dict(log=None, conv_e=1e-11, conv_dm=1e-9)
     r_h = scf.run_scf(inp, scf.HipBackend(inp, fn, device_resident=False), fn, **kw)
     be = scf.HipBackend(inp, fn, device_resident=True)
-    assert be.device_resident and be.eigh.on_device and be.occ_solver is None   # "auto": rotation only from 200 functions
+    assert be.device_resident and be.eigh.on_device and be.occ_solver is None   # "auto": rotation only from 80 functions
     r_d = scf.run_scf(inp, be, fn, **kw)
     # the occupied-subspace rotation forced on, on the device: same loop again
     be_r = scf.HipBackend(inp, fn, device_resident=True, eigensolver="rotate")
@@ -367,6 +367,23 @@ def test_device_resident_scf_matches_the_host_loop(dev, fn, eri_mode):
     assert r_d["E_tot"] == pytest.approx(r_h["E_tot"], abs=1e-9)
     assert r_d["E_xc"] == pytest.approx(r_h["E_xc"], abs=1e-9)
     assert np.abs(r_d["dm"] - r_h["dm"]).max() < 1e-7
+
+
+def test_host_loop_with_the_rotation_solver_on_benzene(dev):
+    """Benzene PBE/def2-SVP (nao 114: "auto" selects the occupied-subspace rotation, host form): same energy, density
+    and cycle count (within one) as eigh(F, S) every cycle, and most cycles are rotations."""
+    from quantum_compute_dft_amd import inputs, scf
+    inp = inputs.build("Benzene", "def2-svp", 3, verbose=False, eri_mode="cholesky", chol_tol=1e-8)
+    be = scf.HipBackend(inp, "GGA")
+    assert not be.device_resident and be.occ_solver is not None and be.occ_solver.host
+    r = scf.run_scf(inp, be, "GGA", log=None)
+    r_x = scf.run_scf(inp, scf.HipBackend(inp, "GGA", eigensolver="exact"), "GGA", log=None)
+    assert r["converged"] and r_x["converged"] and abs(r["cycles"] - r_x["cycles"]) <= 1
+    assert r["E_tot"] == pytest.approx(r_x["E_tot"], abs=2e-8)          # both stop at |dE| < 1e-8
+    assert r["E_tot"] == pytest.approx(-231.77070183, abs=5e-8)          # the value of rounds 1 and 2 (profiles/r0*_scf_*)
+    assert np.abs(r["dm"] - r_x["dm"]).max() < 1e-5                      # ||d dm||_F < 1e-6 is the loop's own threshold
+    st = be.occ_solver.stats
+    assert st["rotated"] >= 10 and st["exact"] <= 4
 
 
 @pytest.mark.parametrize("bname,mol,deriv", [
