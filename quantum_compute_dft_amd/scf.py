@@ -38,22 +38,59 @@ class CDIIS:
             import torch
             self.torch = torch
             self._S = None
+        self._slots = None      # host form: ring of `space` (F, e) pairs in two flat arrays + their Gram matrix
 
-    def _error(self, S, dm, F):
-        if self.dev is None:
-            sdf = S @ dm @ F
-            return F.copy(), (sdf.T - sdf).ravel()
+    def _update_host(self, S, dm, F, cocc=None):
+        """Host form without per-cycle recomputation: the history lives in two (space, n^2) arrays, the Gram
+        matrix gets ONE new row per cycle (a GEMV) and the extrapolation is one GEMV over the stored Fock matrices
+        (the plain form recomputed 36 dot products and summed 8 scaled matrices: 0.25 ms of a 0.87 ms Benzene cycle)."""
+        n2 = F.size
+        if self._slots is None:
+            self._Fb, self._Eb = np.empty((self.space, n2)), np.empty((self.space, n2))
+            self._Gb, self._slots = np.zeros((self.space, self.space)), []
+        slot = self._slots.pop(0) if len(self._slots) == self.space else len(self._slots)   # oldest pair is overwritten
+        # S D F with D = cocc cocc^T: three n^2 n_occ products instead of two n^3 ones (n = 114, 21 occupied: 3.6x fewer flops)
+        sdf = (S @ cocc) @ (cocc.T @ F) if cocc is not None else S @ dm @ F
+        self._Fb[slot] = F.ravel()
+        np.subtract(sdf.T, sdf, out=self._Eb[slot].reshape(F.shape))
+        self._slots.append(slot)
+        idx = np.array(self._slots)
+        row = self._Eb[idx] @ self._Eb[slot] if len(idx) < self.space else self._Eb @ self._Eb[slot]
+        if len(idx) == self.space:
+            row = row[idx]
+        self._Gb[slot, idx] = self._Gb[idx, slot] = row
+        n = len(idx)
+        if n < 2:
+            return F
+        B = np.zeros((n + 1, n + 1)); B[0, 1:] = B[1:, 0] = 1.0
+        B[1:, 1:] = self._Gb[np.ix_(idx, idx)]
+        rhs = np.zeros(n + 1); rhs[0] = 1.0
+        try:
+            c = np.linalg.solve(B, rhs)[1:]
+        except np.linalg.LinAlgError:
+            c = np.linalg.lstsq(B, rhs, rcond=None)[0][1:]
+        cs = np.zeros(self.space); cs[idx] = c
+        return (cs[:max(idx) + 1] @ self._Fb[:max(idx) + 1]).reshape(F.shape)
+
+    def _error(self, S, dm, F, cocc=None):
         t = self.torch
         if self._S is None:
             self._S = t.as_tensor(S, dtype=t.float64, device=self.dev)
         Fd = F.clone() if t.is_tensor(F) else t.as_tensor(F, dtype=t.float64, device=self.dev)
-        sdf = self._S @ t.as_tensor(dm, dtype=t.float64, device=self.dev) @ Fd
+        if cocc is not None:
+            c = t.as_tensor(cocc, dtype=t.float64, device=self.dev)
+            sdf = (self._S @ c) @ (c.T @ Fd)
+        else:
+            sdf = self._S @ t.as_tensor(dm, dtype=t.float64, device=self.dev) @ Fd
         return Fd, (sdf.T - sdf).reshape(-1)
 
-    def update(self, S, dm, F, keep_on_device=False):
+    def update(self, S, dm, F, keep_on_device=False, cocc=None):
         """Extrapolated Fock matrix.  Device mode accepts numpy or device tensors; `keep_on_device` returns
-        the device tensor (device-resident loop) instead of a numpy copy."""
-        Fk, ek = self._error(S, dm, F)
+        the device tensor (device-resident loop) instead of a numpy copy.  `cocc` (n, n_occ) with dm = cocc cocc^T,
+        when the caller has it: the commutator is then formed through the thin factor."""
+        if self.dev is None:
+            return self._update_host(S, dm, F, cocc)
+        Fk, ek = self._error(S, dm, F, cocc)
         self.F.append(Fk); self.e.append(ek)
         if len(self.F) > self.space:
             self.F.pop(0); self.e.pop(0)
@@ -527,7 +564,7 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         if root or sync is None:   # rank 0 is authoritative: DIIS + eigh run once, replicas receive the result
             Vxc = 0.5 * (Vraw + Vraw.T)                                                # dft.py:212
             F = Hcore + J + Vxc - (c_hf * 0.5 * K if K is not None else 0.0)           # dft.py:221,223
-            F = diis.update(S, dm, F)
+            F = diis.update(S, dm, F, cocc=cocc)
             e, C = solve(F)
             cocc_new = np.ascontiguousarray(np.sqrt(2.0) * C)
             dm_new = cocc_new @ cocc_new.T
@@ -600,7 +637,7 @@ def _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
             if want_k:
                 F = F - (0.5 * c_hf) * K                                               # dft.py:221
             mark()
-            F = diis.update(S, dm, F, keep_on_device=True)
+            F = diis.update(S, dm, F, keep_on_device=True, cocc=cocc)
             mark()
             e, cocc_new = eigh_occ(F)
             mark()
