@@ -43,7 +43,7 @@ class CDIIS:
     def _update_host(self, S, dm, F, cocc=None):
         """Host form without per-cycle recomputation: the history lives in two (space, n^2) arrays, the Gram
         matrix gets ONE new row per cycle (a GEMV) and the extrapolation is one GEMV over the stored Fock matrices
-        (the plain form recomputed 36 dot products and summed 8 scaled matrices: 0.25 ms of a 0.87 ms Benzene cycle)."""
+        (the plain form recomputed 36 dot products and summed 8 scaled matrices: 0.12 against 0.07 ms of a Benzene cycle)."""
         n2 = F.size
         if self._slots is None:
             self._Fb, self._Eb = np.empty((self.space, n2)), np.empty((self.space, n2))
