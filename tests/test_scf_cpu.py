@@ -128,3 +128,29 @@ def test_replicas_stay_bitwise_identical_and_stop_in_the_same_cycle(tmp_path):
     inp = inputs.build("H2O", "sto-3g", 1, verbose=False)
     ref = scf.run_scf(inp, OracleBackend(inp, "GGA"), "GGA", log=None, conv_e=1e-10, conv_dm=1e-8)
     assert int(r0["cycles"]) == ref["cycles"] and np.array_equal(r0["dm"], ref["dm"])
+
+
+def test_cdiis_host_form_equals_the_textbook_formula():
+    """The in-place host DIIS (ring of (F, e) pairs, one new Gram row per cycle, commutator through the thin
+    factor) against the plain Pulay formula recomputed from scratch each cycle, past the wrap of the 8-deep history."""
+    rng = np.random.default_rng(11)
+    n, no = 18, 5
+    S = np.eye(n) + 0.02 * (lambda a: a + a.T)(rng.normal(size=(n, n)))
+    hist_F, hist_e = [], []
+    a, b = scf.CDIIS(), scf.CDIIS()
+    for k in range(13):
+        c = rng.normal(size=(n, no)); dm = c @ c.T
+        F = (lambda m: m + m.T)(rng.normal(size=(n, n)))
+        sdf = S @ dm @ F
+        hist_F.append(F.copy()); hist_e.append((sdf.T - sdf).ravel())
+        hist_F, hist_e = hist_F[-8:], hist_e[-8:]
+        m = len(hist_F)
+        if m >= 2:
+            B = np.zeros((m + 1, m + 1)); B[0, 1:] = B[1:, 0] = 1.0
+            B[1:, 1:] = np.array(hist_e) @ np.array(hist_e).T
+            rhs = np.zeros(m + 1); rhs[0] = 1.0
+            ref = np.tensordot(np.linalg.solve(B, rhs)[1:], np.array(hist_F), axes=1)
+        else:
+            ref = F
+        for got in (a.update(S, dm, F), b.update(S, dm, F, cocc=c)):
+            assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
