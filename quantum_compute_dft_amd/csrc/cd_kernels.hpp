@@ -231,29 +231,16 @@ __global__ __launch_bounds__(256) void k_pack_cocc(int nao, int nocc, int ldp, c
     cp[e] = i < nocc ? c[(size_t)r * nocc + i] : 0.0;
 }
 
-// v[P] = sum_ab L[P][a][b] D[a][b]   (one workgroup per vector, fixed summation order).  L_P is symmetric
-// (include/dft_solver.h): only its elements on or above the diagonal are read, against D[a][b] + D[b][a] -- half the
-// bytes of the pass; D itself (any matrix, symmetric or not) stays in L2.
-__global__ __launch_bounds__(256) void k_cd_dot(int n, const double *__restrict__ L,
+// (Reading only the upper triangle of the symmetric L_P against D + D^T halves the bytes but was slower at Benzene's
+// size -- 112 against 89 us for the J step: the index arithmetic and half-idle waves cost more than the bytes save.)
+// v[P] = sum_e L[P][e] D[e]   (one workgroup per vector, fixed summation order)
+__global__ __launch_bounds__(256) void k_cd_dot(long n2, const double *__restrict__ L,
                                                 const double *__restrict__ D, double *__restrict__ v)
 {
     __shared__ double red[256];
-    const long n2 = (long)n * n;
     const double *Lp = L + (size_t)blockIdx.x * n2;
     double s = 0.0;
-    for (long e0 = threadIdx.x; e0 < n2; e0 += 1024) {
-        double l[4], d[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { // four independent loads in flight per thread
-            const long e = e0 + 256 * q;
-            const int a = (int)(e / n), b = (int)(e - (long)a * n);
-            const bool up = e < n2 && b >= a;
-            l[q] = up ? Lp[e] : 0.0;
-            d[q] = up ? (a == b ? D[e] : D[e] + D[(size_t)b * n + a]) : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s += l[q] * d[q];
-    }
+    for (long e = threadIdx.x; e < n2; e += 256) s += Lp[e] * D[e];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {

@@ -446,7 +446,7 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
         if (!reserve(s, s->cdv, sizeof(double) * (size_t)naux * (1 + npair_h), "hipMalloc(cd v)")) return -1;
         if (!fused_dot) {
             ScopedTimer t(s, "cd_dot");
-            hipLaunchKernelGGL(k_cd_dot, dim3((unsigned)naux), dim3(256), 0, st, nao, L, dm, (double *)s->cdv.p);
+            hipLaunchKernelGGL(k_cd_dot, dim3((unsigned)naux), dim3(256), 0, st, n2, L, dm, (double *)s->cdv.p);
         }
     }
     double *v = (double *)s->cdv.p, *vpart = v ? v + naux : nullptr;
