@@ -116,10 +116,11 @@ def cpu_baseline(xc, dm, ao, gr, w, target_seconds):
 
 
 def scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, iters=9, eri="auto"):
-    """One SCF iteration as dft.py:199-236 does it, on the same synthetic shapes, in the form scf.run_scf uses
-    at that size.  Below 400 functions (host LAPACK eigh): ONE pinned upload [dm | cocc], J (+K for B3LYP), XC
-    sweep, ONE pinned download [J | K | Vxc], Fock build + eigh on the host.  From 400 functions:
-    device-resident -- Fock build, hipSOLVER eigh and dm = cocc cocc^T in HBM, one 4-double download.
+    """One SCF iteration as dft.py:199-236 does it -- eigh(F, S) EVERY cycle, the reference's loop -- on the same
+    synthetic shapes (a synthetic Fock sequence says nothing about scf.OccupiedRotation, which the driver uses from 80
+    functions: see scf_real_leg for the real molecule).  Below 400 functions (host LAPACK eigh): ONE pinned upload
+    [dm | cocc], J (+K for B3LYP), XC sweep, ONE pinned download [J | K | Vxc], Fock build + eigh on the host.  From
+    400 functions: device-resident -- Fock build, hipSOLVER eigh and dm = cocc cocc^T in HBM, one 4-double download.
     `eri`: "dense" = one pass over a synthetic dense ERI (the reference's formulation, nao <= 200), "cholesky" =
     6 nao synthetic Cholesky vectors (DFT_ComputeJKFactorized), "auto" = dense up to 200 functions."""
     from quantum_compute_dft_amd.scf import FockDiagonaliser
