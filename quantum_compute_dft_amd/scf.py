@@ -192,15 +192,6 @@ class OccupiedRotation:
         self.U = None
         self.stats = {"exact": 0, "rotated": 0, "inner_steps": 0}
 
-    def _small_eigh(self, M):
-        """eigh of an n_occ x n_occ matrix: on the host (hipSOLVER needs ~1 ms for a 47 x 47 matrix, one LAPACK
-        thread 0.06 ms plus two 17 KB transfers)."""
-        t = self.t
-        if self.dev.type == "cpu":
-            return t.linalg.eigh(M)
-        w, V = np.linalg.eigh(M.cpu().numpy())
-        return t.as_tensor(w, device=self.dev), t.as_tensor(V, device=self.dev)
-
     def _exact(self, F):
         t = self.t
         Fp = self.X.T @ F @ self.X
@@ -238,16 +229,18 @@ class OccupiedRotation:
         d = t.diagonal(A)
         do, dv = d[:no], d[no:]
         Aoo, Aov, Avo, Avv = A[:no, :no], A[:no, no:], A[no:, :no], A[no:, no:]
-        den = dv[:, None] - do[None, :]
-        K = -Avo / den
-        if float(K.abs().max()) > 0.5:
+        rden = 1.0 / (dv[:, None] - do[None, :])
+        K = -(Avo * rden)
+        if not float(K.abs().max()) <= 0.5:
             return self._exact(F)
+        # every operation below is a kernel launch (~8 us each at these sizes, the whole cost of the device form):
+        # fused multiply-adds (addmm / addcmul), a convergence test -- a host sync -- every third step only, and
+        # ONE download / ONE upload for the two n_occ x n_occ eigen-decompositions of the completion
         prev, ok = float("inf"), False
-        every = 1 if self.dev.type == "cpu" else 3      # on the device a convergence test is a host sync: every third step
         for it in range(self.max_inner):
-            R = Avo + Avv @ K - K @ Aoo - K @ (Aov @ K)
+            R = t.addmm(Avo, Avv, K).addmm_(K, t.addmm(Aoo, Aov, K), alpha=-1.0)   # Avo + Avv K - K (Aoo + Aov K)
             self.stats["inner_steps"] += 1
-            if it % every == 0:
+            if it % 3 == 0:
                 r = float(R.abs().max())
                 if r < tol:
                     ok = True
@@ -255,27 +248,32 @@ class OccupiedRotation:
                 if not (r < 4.0 * prev):    # diverging (or NaN)
                     break
                 prev = min(prev, r)
-            K = K - R / den
+            K = t.addcmul(K, R, rden, value=-1.0)
         if not ok:
             return self._exact(F)
-        lam, V = self._small_eigh(K.T @ K)
-        lam = lam.clamp_min(0.0)
-        Mo = (V / t.sqrt(1.0 + lam)) @ V.T                                    # (1 + K^T K)^-1/2
-        g = t.where(lam > 1e-12, (1.0 / t.sqrt(1.0 + lam) - 1.0) / lam.clamp_min(1e-300), t.full_like(lam, -0.5))
-        G = (V * g) @ V.T                                                     # (1 + K K^T)^-1/2 = 1 + K G K^T
-        Uo, Uv = U[:, :no], U[:, no:]
-        T = Uv - Uo @ K.T
-        Uv2 = T + ((T @ K) @ G) @ K.T
-        Uo2 = (Uo + Uv @ K) @ Mo
-        Aoo2 = Mo @ (Aoo + Aov @ K + K.T @ Avo + K.T @ (Avv @ K)) @ Mo        # occupied block in the rotated basis
-        eo, Vo = self._small_eigh(0.5 * (Aoo2 + Aoo2.T))
-        if float(eo[-1]) > float(dv.min()) - 1e-3:                            # aufbau order in doubt
+        Kt = K.T
+        Fo = t.addmm(t.addmm(Aoo, Aov, K), Kt, t.addmm(Avo, Avv, K))          # Y^T F Y in the U basis, Y = Uo + Uv K
+        pack = t.cat([(Kt @ K).reshape(-1), Fo.reshape(-1), dv.min().reshape(1)]).cpu().numpy()
+        M, Foh, dvmin = pack[:no * no].reshape(no, no), pack[no * no:2 * no * no].reshape(no, no), pack[-1]
+        lam, V = np.linalg.eigh(M)
+        lam = np.maximum(lam, 0.0)
+        isq = 1.0 / np.sqrt(1.0 + lam)
+        Mo = (V * isq) @ V.T                                                  # (1 + K^T K)^-1/2
+        G = (V * np.where(lam > 1e-12, (isq - 1.0) / np.maximum(lam, 1e-300), -0.5)) @ V.T   # (1 + K K^T)^-1/2 = 1 + K G K^T
+        Aoo2 = Mo @ Foh @ Mo                                                  # occupied block in the rotated basis
+        eo, Vo = np.linalg.eigh(0.5 * (Aoo2 + Aoo2.T))
+        if eo[-1] > dvmin - 1e-3:                                             # aufbau order in doubt
             return self._exact(F)
-        Uo2 = Uo2 @ Vo                                                        # canonical occupied orbitals
-        self.U = t.cat([Uo2, Uv2], dim=1)
+        up = t.as_tensor(np.concatenate([G.ravel(), (Mo @ Vo).ravel(), eo]), device=self.dev)
+        G_d, c_d, eo_d = up[:no * no].view(no, no), up[no * no:2 * no * no].view(no, no), up[2 * no * no:]
+        Uo, Uv = U[:, :no], U[:, no:]
+        Un = t.empty_like(U)
+        t.mm(t.addmm(Uo, Uv, K), c_d, out=Un[:, :no])                         # canonical occupied orbitals (Uo + Uv K) Mo Vo
+        T = t.addmm(Uv, Uo, Kt, alpha=-1.0)
+        Un[:, no:] = t.addmm(T, (T @ K) @ G_d, Kt)
+        self.U = Un
         self.stats["rotated"] += 1
-        return t.cat([eo, dv]), Uo2
-
+        return t.cat([eo_d, dv]), Un[:, :no]
 
     def _occupied_host(self, F, tol):
         """The same algorithm in numpy (returns numpy arrays): at n = 114 one cycle is ~25 small BLAS/LAPACK calls."""
