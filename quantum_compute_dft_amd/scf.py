@@ -29,99 +29,70 @@ from scipy.linalg import eigh
 
 class CDIIS:
     """Pulay DIIS on the commutator SDF - FDS (PySCF scf.diis.CDIIS as used at dft.py:184,225).
-    With `device` the n^3 products and the history live on the GPU (rocBLAS through torch; only the
-    (space+1)^2 system is solved on the host): n = 494 costs 2.3 ms per cycle on 16 host cores."""
+
+    The history is a ring of `space` (F, e) pairs in two flat (space, n^2) arrays; per cycle the Gram matrix of the
+    error vectors gets ONE new row (a GEMV) and the extrapolation is one GEMV over the stored Fock matrices (the
+    textbook form recomputes 36 dot products and sums 8 scaled matrices: 0.12 against 0.07 ms of a Benzene cycle).
+    The commutator is formed through the thin factor when the caller passes cocc with dm = cocc cocc^T: three
+    n^2 n_occ products instead of two n^3 ones.  With `device` arrays and products live on the GPU (rocBLAS through
+    torch; n = 494 costs 2.3 ms per cycle on 16 host cores) and only the (space+1)^2 system is solved on the host."""
 
     def __init__(self, space=8, device=None):
-        self.space, self.F, self.e, self.dev = space, [], [], device
+        self.space, self.dev = space, device
+        self._slots = None
         if device is not None:
             import torch
             self.torch = torch
-            self._S = None
-        self._slots = None      # host form: ring of `space` (F, e) pairs in two flat arrays + their Gram matrix
 
-    def _update_host(self, S, dm, F, cocc=None):
-        """Host form without per-cycle recomputation: the history lives in two (space, n^2) arrays, the Gram
-        matrix gets ONE new row per cycle (a GEMV) and the extrapolation is one GEMV over the stored Fock matrices
-        (the plain form recomputed 36 dot products and summed 8 scaled matrices: 0.12 against 0.07 ms of a Benzene cycle)."""
-        n2 = F.size
+    def update(self, S, dm, F, keep_on_device=False, cocc=None):
+        """Extrapolated Fock matrix.  Device mode accepts numpy or device tensors; `keep_on_device` returns
+        the device tensor (device-resident loop) instead of a numpy copy."""
+        dev = self.dev is not None
+        if dev:
+            t = self.torch
+            f64 = t.float64
+            conv = lambda a: a if t.is_tensor(a) else t.as_tensor(a, dtype=f64, device=self.dev)
+        n2 = F.shape[0] * F.shape[1]
         if self._slots is None:
-            self._Fb, self._Eb = np.empty((self.space, n2)), np.empty((self.space, n2))
+            if dev:
+                self._Fb, self._Eb = (t.zeros((self.space, n2), dtype=f64, device=self.dev) for _ in range(2))
+                self._S = conv(S)
+            else:
+                self._Fb, self._Eb = np.zeros((self.space, n2)), np.zeros((self.space, n2))
+                self._S = S
             self._Gb, self._slots = np.zeros((self.space, self.space)), []
-        slot = self._slots.pop(0) if len(self._slots) == self.space else len(self._slots)   # oldest pair is overwritten
-        # S D F with D = cocc cocc^T: three n^2 n_occ products instead of two n^3 ones (n = 114, 21 occupied: 3.6x fewer flops)
-        sdf = (S @ cocc) @ (cocc.T @ F) if cocc is not None else S @ dm @ F
-        self._Fb[slot] = F.ravel()
-        np.subtract(sdf.T, sdf, out=self._Eb[slot].reshape(F.shape))
+        slot = self._slots.pop(0) if len(self._slots) == self.space else len(self._slots)   # the oldest pair is overwritten
+        Fk = conv(F) if dev else F
+        if cocc is not None:
+            c = conv(cocc) if dev else cocc
+            sdf = (self._S @ c) @ (c.T @ Fk)
+        else:
+            sdf = self._S @ (conv(dm) if dev else dm) @ Fk
+        self._Fb[slot] = Fk.reshape(-1)
+        if dev:
+            t.sub(sdf.T, sdf, out=self._Eb[slot].view(F.shape))
+        else:
+            np.subtract(sdf.T, sdf, out=self._Eb[slot].reshape(F.shape))
         self._slots.append(slot)
         idx = np.array(self._slots)
-        row = self._Eb[idx] @ self._Eb[slot] if len(idx) < self.space else self._Eb @ self._Eb[slot]
-        if len(idx) == self.space:
-            row = row[idx]
-        self._Gb[slot, idx] = self._Gb[idx, slot] = row
+        row = self._Eb @ self._Eb[slot]          # against every slot; unused ones are zero and never read
+        row = row.cpu().numpy() if dev else row
+        self._Gb[slot, idx] = self._Gb[idx, slot] = row[idx]
         n = len(idx)
         if n < 2:
-            return F
+            return (Fk if keep_on_device else F)
         B = np.zeros((n + 1, n + 1)); B[0, 1:] = B[1:, 0] = 1.0
         B[1:, 1:] = self._Gb[np.ix_(idx, idx)]
         rhs = np.zeros(n + 1); rhs[0] = 1.0
         try:
-            c = np.linalg.solve(B, rhs)[1:]
+            cf = np.linalg.solve(B, rhs)[1:]
         except np.linalg.LinAlgError:
-            c = np.linalg.lstsq(B, rhs, rcond=None)[0][1:]
-        cs = np.zeros(self.space); cs[idx] = c
-        return (cs[:max(idx) + 1] @ self._Fb[:max(idx) + 1]).reshape(F.shape)
-
-    def _error(self, S, dm, F, cocc=None):
-        t = self.torch
-        if self._S is None:
-            self._S = t.as_tensor(S, dtype=t.float64, device=self.dev)
-        Fd = F.clone() if t.is_tensor(F) else t.as_tensor(F, dtype=t.float64, device=self.dev)
-        if cocc is not None:
-            c = t.as_tensor(cocc, dtype=t.float64, device=self.dev)
-            sdf = (self._S @ c) @ (c.T @ Fd)
-        else:
-            sdf = self._S @ t.as_tensor(dm, dtype=t.float64, device=self.dev) @ Fd
-        return Fd, (sdf.T - sdf).reshape(-1)
-
-    def update(self, S, dm, F, keep_on_device=False, cocc=None):
-        """Extrapolated Fock matrix.  Device mode accepts numpy or device tensors; `keep_on_device` returns
-        the device tensor (device-resident loop) instead of a numpy copy.  `cocc` (n, n_occ) with dm = cocc cocc^T,
-        when the caller has it: the commutator is then formed through the thin factor."""
-        if self.dev is None:
-            return self._update_host(S, dm, F, cocc)
-        Fk, ek = self._error(S, dm, F, cocc)
-        self.F.append(Fk); self.e.append(ek)
-        if len(self.F) > self.space:
-            self.F.pop(0); self.e.pop(0)
-            if self.dev is not None:
-                self._G = self._G[1:, 1:]
-        n = len(self.F)
-        if self.dev is not None:   # Gram matrix of the error vectors: only the new row (one GEMV on the GPU)
-            row = (self.torch.stack(self.e) @ ek).cpu().numpy()
-            G = np.zeros((n, n))
-            G[:n - 1, :n - 1] = getattr(self, "_G", np.zeros((0, 0)))[:n - 1, :n - 1]
-            G[n - 1, :] = G[:, n - 1] = row
-            self._G = G
-        if n < 2:
-            return Fk if keep_on_device else F
-        B = np.zeros((n + 1, n + 1)); B[0, 1:] = B[1:, 0] = 1.0
-        if self.dev is None:
-            for i in range(n):
-                for j in range(i + 1):
-                    B[i + 1, j + 1] = B[j + 1, i + 1] = self.e[i] @ self.e[j]
-        else:
-            B[1:, 1:] = self._G
-        rhs = np.zeros(n + 1); rhs[0] = 1.0
-        try:
-            c = np.linalg.solve(B, rhs)[1:]
-        except np.linalg.LinAlgError:
-            c = np.linalg.lstsq(B, rhs, rcond=None)[0][1:]
-        if self.dev is None:
-            return sum(ci * Fi for ci, Fi in zip(c, self.F))
-        out = self.torch.zeros_like(self.F[0])
-        for ci, Fi in zip(c, self.F):
-            out.add_(Fi, alpha=float(ci))
+            cf = np.linalg.lstsq(B, rhs, rcond=None)[0][1:]
+        m = int(idx.max()) + 1
+        cs = np.zeros(m); cs[idx] = cf
+        if not dev:
+            return (cs @ self._Fb[:m]).reshape(F.shape)
+        out = (t.as_tensor(cs, device=self.dev) @ self._Fb[:m]).view(F.shape)
         return out if keep_on_device else out.cpu().numpy()
 
 
@@ -640,8 +611,9 @@ def _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
             e, cocc_new = eigh_occ(F)
             mark()
             dm_new = cocc_new @ cocc_new.T
-            scal = t.stack([(dm_new * H).sum(), 0.5 * (dm_new * J).sum(),
-                            (-0.25 * c_hf) * (dm_new * K).sum() if want_k else t.zeros((), dtype=f64, device=dev),
+            dv = dm_new.reshape(-1)
+            tr = backend._down.view(3, -1) @ dv                # [J:D, K:D, Vraw:D] in one launch (J, K, V are its rows)
+            scal = t.stack([t.dot(dv, H.reshape(-1)), 0.5 * tr[0], (-0.25 * c_hf if want_k else 0.0) * tr[1],
                             t.linalg.norm(dm_new - dm)])
             mark()
             if prof is not None and len(tp) == 5:
