@@ -144,6 +144,9 @@ class OccupiedRotation:
     its side of the next cycle's denominators is exact.  Falls back to the full solver (which also does the first
     cycle) when the first-order rotation exceeds 0.5, the fixed point has not reached `tol` in `max_inner` steps or
     grows, or the aufbau order is in doubt (highest occupied level within 1e-3 Ha of the lowest virtual diagonal).
+    The virtual block is never diagonalised, so that test is a necessary one only: run_scf therefore checks the
+    CONVERGED state once against eigh(F, S) (which also supplies the full spectrum it reports) and resumes with the
+    full solver and a fresh DIIS history if the occupied space it followed is not the aufbau one.
 
     Where it pays (profiles/r02_eigensolver.txt): solved to 1e-10 the fixed point needs 15-20 steps in the middle of
     an SCF run (the Fock matrix still moves by 1e-2) and 4-6 at its end; stopped at 1e-3 x the last density change
@@ -501,8 +504,10 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
 
     last_ddm = [None]
 
+    rot = [occ is not None]   # cleared if the converged state fails the check against the full solver (below)
+
     def solve(F):   # (orbital energies, C_occ): the loop never uses the virtual orbitals (dft.py:182,228)
-        if occ is not None:
+        if rot[0]:
             e_, co_ = occ.occupied(F, None if last_ddm[0] is None else 1e-3 * last_ddm[0])
             return np.asarray(e_), np.asarray(co_)
         e_, C_ = solve_full(F)
@@ -552,8 +557,27 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         res.update(E_tot=E_tot, E_one=E_one, E_coul=E_coul, E_xc=E_xc, E_ex_hf=E_ex, cycles=cycle + 1,
                    dm=dm_new, mo_energy=e)
         if abs(dE) < conv_e and ddm < conv_dm:                                         # dft.py:243; same scalars on every rank
-            res["converged"] = True
-            break
+            # The rotation solver follows the occupied space continuously; that it is still the AUFBAU one is checked
+            # once, here, against eigh(F, S) of the converged Fock matrix (which also supplies the exact orbital
+            # energies).  A mismatch (an occupied/virtual level crossing it followed through) resumes the loop with the
+            # full solver -- the reference's loop.  Rank 0 decides, every rank hears it.
+            ok = np.ones(1)
+            if rot[0]:
+                if root or sync is None:
+                    e_x, C_x = solve_full(F)
+                    e_x, C_x = np.asarray(e_x), np.asarray(C_x)
+                    ok[0] = float(np.linalg.norm(2.0 * C_x[:, :nocc] @ C_x[:, :nocc].T - dm_new) < 1e-4)
+                    if ok[0]:
+                        res["mo_energy"] = e_x
+                if sync:
+                    sync.broadcast_numpy([ok])
+            if ok[0]:
+                res["converged"] = True
+                break
+            rot[0] = False
+            diis = CDIIS(device=getattr(backend, "diis_device", None))   # its history belongs to the other state
+            if log:
+                log("     converged occupied space is not the aufbau one: continuing with eigh(F, S) every cycle")
         dm, cocc, E_old = dm_new, cocc_new, E_tot
     return _finish(res, t_start, xc_times, jk_times, it_times)
 
@@ -573,12 +597,21 @@ def _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
 
     last_ddm = [None]
 
+    rot = [backend.occ_solver is not None]   # see the convergence check in _run_scf
+
+    def eigh_full(F):
+        if X.shape[0] < 400:      # as OccupiedRotation._exact: one host LAPACK thread beats hipSOLVER below ~400 functions
+            e_, Cp = eigh((X.T @ F @ X).cpu().numpy(), driver="evd")
+            return t.as_tensor(e_, device=dev), X @ t.as_tensor(Cp, device=dev)
+        e_, Cp = t.linalg.eigh(X.T @ F @ X)
+        return e_, X @ Cp
+
     def eigh_occ(F):                                                                   # dft.py:181,227 on the device
-        if backend.occ_solver is not None:
+        if rot[0]:
             e, co = backend.occ_solver.occupied(F, None if last_ddm[0] is None else 1e-3 * last_ddm[0])
             return e, co * sqrt2
-        e, Cp = t.linalg.eigh(X.T @ F @ X)
-        return e, (X @ Cp[:, :nocc]) * sqrt2
+        e, C = eigh_full(F)
+        return e, C[:, :nocc] * sqrt2
 
     e, cocc = eigh_occ(H)
     dm = cocc @ cocc.T
@@ -631,9 +664,23 @@ def _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
             log(f"{cycle + 1:4d} {E_tot:18.8f} {dE:15.6e} {ddm:15.6e} {E_ex:12.6f}")
         res.update(E_tot=E_tot, E_one=E_one, E_coul=E_coul, E_xc=E_xc, E_ex_hf=E_ex, cycles=cycle + 1)
         if abs(dE) < conv_e and ddm < conv_dm:
-            res["converged"] = True
-            dm = dm_new
-            break
+            ok = t.ones(1, dtype=f64, device=dev)
+            if rot[0]:                                                                 # as in _run_scf
+                if root or sync is None:
+                    e_x, C_x = eigh_full(F)
+                    ok[0] = float(float(t.linalg.norm(2.0 * C_x[:, :nocc] @ C_x[:, :nocc].T - dm_new)) < 1e-4)
+                    if float(ok[0]):
+                        e = e_x
+                if sync:
+                    sync.broadcast([ok])
+            if float(ok[0]):
+                res["converged"] = True
+                dm = dm_new
+                break
+            rot[0] = False
+            diis = CDIIS(device=dev)
+            if log:
+                log("     converged occupied space is not the aufbau one: continuing with eigh(F, S) every cycle")
         dm, cocc, E_old = dm_new, cocc_new, E_tot
     res["dm"] = dm.cpu().numpy()
     res["mo_energy"] = e.cpu().numpy()

@@ -154,3 +154,57 @@ def test_cdiis_host_form_equals_the_textbook_formula():
             ref = F
         for got in (a.update(S, dm, F), b.update(S, dm, F, cocc=c)):
             assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
+def test_converged_state_is_checked_against_the_full_solver(water):
+    """A solver that follows a NON-aufbau occupied space (here: HOMO and LUMO swapped on purpose) converges
+    self-consistently; the loop checks the converged state once against eigh(F, S), sees the mismatch and resumes as
+    the reference's loop (full solver, fresh DIIS history).  Backend with a density-independent Fock matrix (J = 0,
+    Vxc = 0), so both fixed points are known exactly."""
+    from scipy.linalg import eigh as _eigh
+
+    class Swapped:
+        host, stats = True, {"exact": 0, "rotated": 0, "inner_steps": 0}
+
+        def __init__(self, S, nocc):
+            self.S, self.no, self.calls = S, nocc, 0
+
+        def occupied(self, F, accuracy=None):
+            self.calls += 1
+            e, C = _eigh(F, self.S)
+            keep = list(range(self.no - 1)) + [self.no]          # LUMO instead of HOMO
+            return e, C[:, keep]
+
+    class CoreOnly:
+        rank = 0
+
+        def __init__(self, n):
+            self.n = n
+
+        def set_dm(self, dm):
+            pass
+
+        def jk(self, want_k):
+            return np.zeros((self.n, self.n)), None
+
+        def xc(self):
+            return 0.0, np.zeros((self.n, self.n)), 0.0
+
+    n, no = water.S.shape[0], water.nocc
+    e, C = _eigh(water.Hcore, water.S)
+    be = CoreOnly(n)
+    be.occ_solver = Swapped(water.S, no)
+    lines = []
+    r = scf.run_scf(water, be, "LDA", log=lines.append)
+    text = [str(l) for l in lines]
+    assert r["converged"] and sum("not the aufbau one" in l for l in text) == 1
+    assert r["E_tot"] == pytest.approx(2.0 * e[:no].sum() + water.E_nuc, abs=1e-9)           # the aufbau fixed point
+    assert np.abs(r["dm"] - 2.0 * C[:, :no] @ C[:, :no].T).max() < 1e-9
+    assert np.abs(r["mo_energy"] - e).max() < 1e-9
+    calls = be.occ_solver.calls
+    assert 2 <= calls < r["cycles"] + 1                          # the swapped solver was dropped at the check
+    # and a solver that IS right passes the check without a detour, reporting the full spectrum
+    be2 = CoreOnly(n)
+    be2.occ_solver = scf.OccupiedRotation(water.S, no)
+    r2 = scf.run_scf(water, be2, "LDA", log=None)
+    assert r2["converged"] and r2["cycles"] <= 3 and np.abs(r2["mo_energy"] - e).max() < 1e-9
