@@ -152,6 +152,25 @@ int DFT_EvalAO(XCSolver *solver, long long ngrid, int nao, int nshell,
                unsigned long long d_ao_ptr,
                unsigned long long d_ao_grad_ptr);
 
+/* The whole AO -> rho -> XC -> Vxc sweep without resident AO planes ("fused mode"): what
+ * grid.py:30,38 + dft.py:155,172 + DFT_ComputeXC do together, chunk by chunk -- the AO values and gradients of
+ * `chunk_points` grid points (0 = automatic: ~96 MB of planes, an Infinity-Cache-sized working set) are evaluated into
+ * a workspace of the solver, swept, and overwritten by the next chunk; Vxc and Exc add up over the chunks (the
+ * sweep is linear in the grid points).  Memory: chunk_points*nao*(1 or 4) doubles instead of ngrid*nao*(1 or 4)
+ * (BASELINE config 5: 53 GB resident); cost: the AO evaluation is repeated in every call.  Shell table as for
+ * DFT_EvalAO; coords (ngrid,3), weights (ngrid), dm (nao,nao) device in; vxc (nao,nao) and exc (1 double, may be 0)
+ * device out, valid after the work queued on the solver's stream completes (as DFT_ComputeXCAsync).  0 on success. */
+int DFT_ComputeXCDirect(XCSolver *solver, long long ngrid, int nao, int nshell,
+                        const double *shl_xyz, const int *shl_l, const int *shl_nprim,
+                        const int *shl_off, const int *shl_ao,
+                        const double *prim_exp, const double *prim_coef, int nprim_total,
+                        unsigned long long d_coords_ptr,
+                        unsigned long long d_weights_ptr,
+                        unsigned long long d_dm_ptr,
+                        unsigned long long d_vxc_ptr,
+                        unsigned long long d_exc_ptr,
+                        long long chunk_points);
+
 /* Options: "quirks" (1 = reference formulas as shipped, default; 0 = corrected
  * VWN5 / PBE-c derivatives), "path" (0 = auto: wave-specialised
  * persistent MFMA kernels for nao <= 128, generic MFMA kernels above; 1 =

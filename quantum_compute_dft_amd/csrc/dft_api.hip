@@ -60,7 +60,7 @@ struct XCSolver {
     int dbg = 0;       // diagnostics only (ablations of the sixteen-wave kernels: 1 = no plane loads, 2 = no MFMAs)
     int ws_waves = 0;  // wave-specialised kernels (nao <= 128): 0 auto, 8 = 4+4 waves per workgroup, 16 = 8+8
     // workspace
-    DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells, msym, cdy, cdc, cdv;
+    DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells, msym, cdy, cdc, cdv, ao_ws, vtmp;
     int spin_wait = 1; // poll the host-mapped Exc instead of sleeping in hipStreamSynchronize
     int strict_sync = 0; // 1: after the Exc word, also poll the stream until it reports complete (+8-10 us per call)
     double *h_exc = nullptr;   // pinned, host-mapped: the reduce kernel writes Exc here
@@ -522,6 +522,111 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
     return hip_ok(s, hipGetLastError(), "factorised J/K launch") ? 0 : -1;
 }
 
+// The AO shell table on the device: validated, packed and uploaded once per distinct table
+// ([AoShell x nshell][exp x nprim][coef x nprim][AoChunk x nchunk][order x nshell]).
+struct AoTable {
+    const AoShell *sh; const double *exp, *coef; const AoChunk *chunks; const int *order;
+    int nshell, nprim, nchunk, maxcol; bool even_blocks;
+};
+
+bool prepare_ao_table(XCSolver *s, int nao, int nshell, const double *shl_xyz, const int *shl_l, const int *shl_nprim,
+                      const int *shl_off, const int *shl_ao, const double *prim_exp, const double *prim_coef, int nprim_total,
+                      AoTable &out)
+{
+    if (nao <= 0 || nshell <= 0 || nprim_total <= 0) {
+        set_error(s, "bad AO sizes");
+        return false;
+    }
+    int next_col = 0;
+    std::vector<AoChunk> chunks;
+    for (int i = 0; i < nshell; ++i) {
+        const int l = shl_l[i], nf = 2 * l + 1;
+        if (l < 0 || l > AO_MAX_L) { set_error(s, "shell %d: l=%d unsupported (max %d)", i, l, AO_MAX_L); return false; }
+        if (shl_nprim[i] <= 0 || shl_off[i] < 0 || shl_off[i] + shl_nprim[i] > nprim_total) { set_error(s, "shell %d: primitive range out of bounds", i); return false; }
+        if (shl_ao[i] != next_col) { set_error(s, "shell %d: AO columns must be contiguous and ascending (expected %d, got %d)", i, next_col, shl_ao[i]); return false; }
+        if (chunks.empty()) {
+            chunks.push_back(AoChunk{i, i, next_col, 0});
+        } else if (chunks.back().ncol + nf > AO_CW) {
+            // new column block; keep its first column even (16-byte stores) by taking the previous
+            // shell along when needed -- every shell has an odd width, so that flips the parity
+            AoChunk &b = chunks.back();
+            if ((next_col & 1) && b.shell_hi - b.shell_lo >= 2) {
+                const int pf = 2 * shl_l[i - 1] + 1;
+                b.shell_hi -= 1;
+                b.ncol -= pf;
+                chunks.push_back(AoChunk{i - 1, i, next_col - pf, pf});
+            } else {
+                chunks.push_back(AoChunk{i, i, next_col, 0});
+            }
+        }
+        chunks.back().shell_hi = i + 1;
+        chunks.back().ncol += nf;
+        next_col += nf;
+    }
+    if (next_col != nao) { set_error(s, "shell table covers %d AO columns, nao=%d", next_col, nao); return false; }
+    const int nchunk = (int)chunks.size();
+    int maxcol = 0;
+    bool even = true;
+    std::vector<int> order(nshell);
+    for (const AoChunk &c : chunks) {
+        maxcol = std::max(maxcol, c.ncol);
+        if (c.col_lo & 1) even = false;
+        for (int i = c.shell_lo; i < c.shell_hi; ++i) order[i] = i;
+        std::stable_sort(order.begin() + c.shell_lo, order.begin() + c.shell_hi, [&](int a, int b) {
+            return shl_l[a] != shl_l[b] ? shl_l[a] < shl_l[b] : shl_nprim[a] < shl_nprim[b];
+        });
+    }
+    const size_t off_exp = sizeof(AoShell) * nshell;
+    const size_t off_chunk = off_exp + 2 * sizeof(double) * nprim_total;
+    const size_t off_order = off_chunk + sizeof(AoChunk) * nchunk;
+    const size_t bytes = off_order + sizeof(int) * nshell;
+    std::vector<unsigned char> blob(bytes);
+    AoShell *sh = (AoShell *)blob.data();
+    for (int i = 0; i < nshell; ++i) {
+        sh[i].x = shl_xyz[3 * i]; sh[i].y = shl_xyz[3 * i + 1]; sh[i].z = shl_xyz[3 * i + 2];
+        sh[i].l = shl_l[i]; sh[i].nprim = shl_nprim[i]; sh[i].off = shl_off[i]; sh[i].ao = shl_ao[i];
+    }
+    double *pe = (double *)(blob.data() + off_exp);
+    memcpy(pe, prim_exp, sizeof(double) * nprim_total);
+    memcpy(pe + nprim_total, prim_coef, sizeof(double) * nprim_total);
+    memcpy(blob.data() + off_chunk, chunks.data(), sizeof(AoChunk) * nchunk);
+    memcpy(blob.data() + off_order, order.data(), sizeof(int) * nshell);
+    if (blob != s->shell_blob) {
+        if (!reserve(s, s->shells, bytes, "hipMalloc(shells)")) return false;
+        if (!hip_ok(s, hipMemcpyAsync(s->shells.p, blob.data(), bytes, hipMemcpyHostToDevice, s->stream), "upload shells") ||
+            !hip_ok(s, hipStreamSynchronize(s->stream), "synchronise"))
+            return false;
+        s->shell_blob.swap(blob);
+    }
+    const unsigned char *base = (const unsigned char *)s->shells.p;
+    out.sh = (const AoShell *)base;
+    out.exp = (const double *)(base + off_exp);
+    out.coef = out.exp + nprim_total;
+    out.chunks = (const AoChunk *)(base + off_chunk);
+    out.order = (const int *)(base + off_order);
+    out.nshell = nshell; out.nprim = nprim_total; out.nchunk = nchunk; out.maxcol = maxcol; out.even_blocks = even;
+    return true;
+}
+
+void launch_ao(XCSolver *s, const AoTable &t, long ngrid, int nao, const double *coords, double *ao, double *ao_grad)
+{
+    const bool vec = t.even_blocks && (nao % 2 == 0) && ((uintptr_t)ao % 16 == 0) && ((uintptr_t)ao_grad % 16 == 0);
+    // 16 points per workgroup unless their LDS tile would leave fewer than three workgroups per CU
+    // (measured, Benzene: def2-SVP deriv 1 139 -> 122 us with 8; STO-3G and deriv 0 are 10 % faster with 16)
+    const int ao_pt = s->ao_pt ? s->ao_pt : ((ao_grad ? 4 : 1) * 16 * (t.maxcol | 1) * 8 > 53 * 1024 ? 8 : 16);
+    launch_eval_ao(s->stream, ngrid, nao, t.nchunk, t.maxcol, vec, ao_pt, s->num_cu, t.nshell, t.nprim, t.sh, t.exp, t.coef, t.chunks, t.order,
+                   coords, ao, ao_grad);
+}
+
+// V (+)= V_chunk, Exc (+)= Exc_chunk: the grid chunks of the direct sweep add up by linearity in the grid points
+__global__ void k_accumulate_chunk(long n2, int add, const double *__restrict__ vc, const double *__restrict__ ec,
+                                   double *__restrict__ v, double *__restrict__ e)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n2) v[i] = add ? v[i] + vc[i] : vc[i];
+    if (i == 0) *e = add ? *e + *ec : *ec;
+}
+
 } // namespace
 
 extern "C" {
@@ -566,7 +671,7 @@ void DFT_DestroySolver(XCSolver *s)
         (void)hipStreamSynchronize(s->stream);
         DevBuf *bufs[] = {&s->dsym, &s->rho, &s->sigma, &s->grad, &s->coef, &s->partial,
                           &s->slabs, &s->exc, &s->jpart, &s->kpart, &s->shells, &s->msym,
-                          &s->cdy, &s->cdc, &s->cdv};
+                          &s->cdy, &s->cdc, &s->cdv, &s->ao_ws, &s->vtmp};
         for (DevBuf *b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (s->h_exc) (void)hipHostFree(s->h_exc);
@@ -700,85 +805,51 @@ int DFT_EvalAO(XCSolver *s, long long ngrid, int nao, int nshell, const double *
     s->last_error.clear();
     s->n_timed = 0;
     if (!s->device_ok) { set_error(s, "no usable HIP device"); return -1; }
-    if (ngrid <= 0 || nao <= 0 || nshell <= 0 || nprim_total <= 0) {
-        set_error(s, "bad AO sizes");
-        return -1;
-    }
-    // validate, then pack: [AoShell x nshell][exp x nprim][coef x nprim][AoChunk x nchunk][order x nshell]
-    int next_col = 0;
-    std::vector<AoChunk> chunks;
-    for (int i = 0; i < nshell; ++i) {
-        const int l = shl_l[i], nf = 2 * l + 1;
-        if (l < 0 || l > AO_MAX_L) { set_error(s, "shell %d: l=%d unsupported (max %d)", i, l, AO_MAX_L); return -1; }
-        if (shl_nprim[i] <= 0 || shl_off[i] < 0 || shl_off[i] + shl_nprim[i] > nprim_total) { set_error(s, "shell %d: primitive range out of bounds", i); return -1; }
-        if (shl_ao[i] != next_col) { set_error(s, "shell %d: AO columns must be contiguous and ascending (expected %d, got %d)", i, next_col, shl_ao[i]); return -1; }
-        if (chunks.empty()) {
-            chunks.push_back(AoChunk{i, i, next_col, 0});
-        } else if (chunks.back().ncol + nf > AO_CW) {
-            // new column block; keep its first column even (16-byte stores) by taking the previous
-            // shell along when needed -- every shell has an odd width, so that flips the parity
-            AoChunk &b = chunks.back();
-            if ((next_col & 1) && b.shell_hi - b.shell_lo >= 2) {
-                const int pf = 2 * shl_l[i - 1] + 1;
-                b.shell_hi -= 1;
-                b.ncol -= pf;
-                chunks.push_back(AoChunk{i - 1, i, next_col - pf, pf});
-            } else {
-                chunks.push_back(AoChunk{i, i, next_col, 0});
-            }
-        }
-        chunks.back().shell_hi = i + 1;
-        chunks.back().ncol += nf;
-        next_col += nf;
-    }
-    if (next_col != nao) { set_error(s, "shell table covers %d AO columns, nao=%d", next_col, nao); return -1; }
-    const int nchunk = (int)chunks.size();
-    int maxcol = 0;
-    bool vec = (nao % 2 == 0) && (d_ao % 16 == 0) && (d_ao_grad % 16 == 0);
-    std::vector<int> order(nshell);
-    for (const AoChunk &c : chunks) {
-        maxcol = std::max(maxcol, c.ncol);
-        if (c.col_lo & 1) vec = false;
-        for (int i = c.shell_lo; i < c.shell_hi; ++i) order[i] = i;
-        std::stable_sort(order.begin() + c.shell_lo, order.begin() + c.shell_hi, [&](int a, int b) {
-            return shl_l[a] != shl_l[b] ? shl_l[a] < shl_l[b] : shl_nprim[a] < shl_nprim[b];
-        });
-    }
-    const size_t off_exp = sizeof(AoShell) * nshell;
-    const size_t off_chunk = off_exp + 2 * sizeof(double) * nprim_total;
-    const size_t off_order = off_chunk + sizeof(AoChunk) * nchunk;
-    const size_t bytes = off_order + sizeof(int) * nshell;
-    std::vector<unsigned char> blob(bytes);
-    AoShell *sh = (AoShell *)blob.data();
-    for (int i = 0; i < nshell; ++i) {
-        sh[i].x = shl_xyz[3 * i]; sh[i].y = shl_xyz[3 * i + 1]; sh[i].z = shl_xyz[3 * i + 2];
-        sh[i].l = shl_l[i]; sh[i].nprim = shl_nprim[i]; sh[i].off = shl_off[i]; sh[i].ao = shl_ao[i];
-    }
-    double *pe = (double *)(blob.data() + off_exp);
-    memcpy(pe, prim_exp, sizeof(double) * nprim_total);
-    memcpy(pe + nprim_total, prim_coef, sizeof(double) * nprim_total);
-    memcpy(blob.data() + off_chunk, chunks.data(), sizeof(AoChunk) * nchunk);
-    memcpy(blob.data() + off_order, order.data(), sizeof(int) * nshell);
-    if (blob != s->shell_blob) {
-        if (!reserve(s, s->shells, bytes, "hipMalloc(shells)")) return -1;
-        if (!hip_ok(s, hipMemcpyAsync(s->shells.p, blob.data(), bytes, hipMemcpyHostToDevice, s->stream), "upload shells") ||
-            !hip_ok(s, hipStreamSynchronize(s->stream), "synchronise"))
-            return -1;
-        s->shell_blob.swap(blob);
-    }
-    const unsigned char *base = (const unsigned char *)s->shells.p;
-    const AoShell *dsh = (const AoShell *)base;
-    const double *dexp = (const double *)(base + off_exp);
-    const double *dcoef = dexp + nprim_total;
-    const AoChunk *dchunks = (const AoChunk *)(base + off_chunk);
-    const int *dorder = (const int *)(base + off_order);
-    // 16 points per workgroup unless their LDS tile would leave fewer than three workgroups per CU
-    // (measured, Benzene: def2-SVP deriv 1 139 -> 122 us with 8; STO-3G and deriv 0 are 10 % faster with 16)
-    const int ao_pt = s->ao_pt ? s->ao_pt : ((d_ao_grad ? 4 : 1) * 16 * (maxcol | 1) * 8 > 53 * 1024 ? 8 : 16);
+    if (ngrid <= 0) { set_error(s, "bad AO sizes"); return -1; }
+    AoTable tab;
+    if (!prepare_ao_table(s, nao, nshell, shl_xyz, shl_l, shl_nprim, shl_off, shl_ao, prim_exp, prim_coef, nprim_total, tab)) return -1;
     ScopedTimer t(s, "eval_ao");
-    launch_eval_ao(s->stream, (long)ngrid, nao, nchunk, maxcol, vec, ao_pt, s->num_cu, nshell, nprim_total, dsh, dexp, dcoef, dchunks, dorder,
-                   (const double *)d_coords, (double *)d_ao, (double *)d_ao_grad);
+    launch_ao(s, tab, (long)ngrid, nao, (const double *)d_coords, (double *)d_ao, (double *)d_ao_grad);
     return hip_ok(s, hipGetLastError(), "AO launch") ? 0 : -1;
+}
+
+int DFT_ComputeXCDirect(XCSolver *s, long long ngrid, int nao, int nshell, const double *shl_xyz,
+                        const int *shl_l, const int *shl_nprim, const int *shl_off, const int *shl_ao,
+                        const double *prim_exp, const double *prim_coef, int nprim_total,
+                        unsigned long long d_coords, unsigned long long d_w, unsigned long long d_dm,
+                        unsigned long long d_vxc, unsigned long long d_exc, long long chunk_points)
+{
+    if (!s) return -1;
+    DeviceGuard dg(s);
+    s->last_error.clear();
+    if (!s->device_ok) { set_error(s, "no usable HIP device"); return -1; }
+    if (ngrid <= 0 || nao <= 0 || !d_coords || !d_w || !d_dm || !d_vxc) { set_error(s, "bad arguments to DFT_ComputeXCDirect"); return -1; }
+    AoTable tab;
+    if (!prepare_ao_table(s, nao, nshell, shl_xyz, shl_l, shl_nprim, shl_off, shl_ao, prim_exp, prim_coef, nprim_total, tab)) return -1;
+    const bool gga = s->type != SOLVER_LDA;
+    const int nplane = gga ? 4 : 1;
+    // chunk: its planes stay within ~96 MB (they are written by the AO kernel and read twice right after: an
+    // Infinity-Cache-sized working set), but never fewer than 64 sixteen-point tiles per CU; a multiple of 256
+    long chunk = chunk_points > 0 ? (long)chunk_points : std::max<long>((long)(96.0e6 / (8.0 * nao * nplane)), 1024L * s->num_cu);
+    chunk = std::min<long>(((chunk + 255) / 256) * 256, (long)ngrid);
+    const size_t plane = (size_t)chunk * nao;
+    if (!reserve(s, s->ao_ws, sizeof(double) * plane * nplane, "hipMalloc(AO chunk)") ||
+        !reserve(s, s->vtmp, sizeof(double) * ((size_t)nao * nao + 1), "hipMalloc(V chunk)"))
+        return -1;
+    double *wao = (double *)s->ao_ws.p, *vt = (double *)s->vtmp.p, *eacc = vt + (size_t)nao * nao;
+    const double *coords = (const double *)d_coords, *w = (const double *)d_w;
+    const unsigned nb = (unsigned)(((size_t)nao * nao + 255) / 256);
+    for (long g0 = 0; g0 < (long)ngrid; g0 += chunk) {
+        const long n = std::min<long>(chunk, (long)ngrid - g0);
+        double *wgr = gga ? wao + (size_t)n * nao : nullptr;       // (3, n, nao) right behind the values of THIS chunk
+        launch_ao(s, tab, n, nao, coords + 3 * g0, wao, wgr);
+        if (!xc_sweep(s, n, nao, (const double *)d_dm, wao, wgr, w + g0, vt, false)) return -1;
+        hipLaunchKernelGGL(k_accumulate_chunk, dim3(nb), dim3(256), 0, s->stream, (long)nao * nao, g0 == 0 ? 0 : 1, vt,
+                           (const double *)s->exc.p, (double *)d_vxc, eacc);
+    }
+    if (d_exc && !hip_ok(s, hipMemcpyAsync((void *)d_exc, eacc, sizeof(double), hipMemcpyDeviceToDevice, s->stream), "copy Exc"))
+        return -1;
+    return hip_ok(s, hipGetLastError(), "direct XC sweep launch") ? 0 : -1;
 }
 
 int DFT_SetOption(XCSolver *s, const char *key, double value)

@@ -29,6 +29,9 @@ def main(argv=None):
     p.add_argument("--device-resident", type=int, default=-1,
                    help="1: Fock build, DIIS, eigh and the density stay in HBM (only scalars cross PCIe per cycle); "
                         "0: host loop (one pinned transfer each way per cycle); -1 (default): device from 200 basis functions")
+    p.add_argument("--ao", default="resident", choices=["resident", "direct"],
+                   help="resident: AO values and gradients of the whole grid stay in HBM (the reference's layout, dft.py:155,172); "
+                        "direct: they are re-evaluated chunk by chunk inside every XC call (DFT_ComputeXCDirect), memory ~100 MB")
     p.add_argument("--both-quirks", action="store_true",
                    help="LDA/GGA: run the SCF twice, with the reference's formulas as shipped (its CUDA path) and with the "
                         "corrected VWN5 / PBE-c derivatives (what PySCF's slater,vwn5 / PBE,PBE compute), and report both energies")
@@ -76,7 +79,7 @@ def main(argv=None):
     try:
         backend = scf.HipBackend(inp, args.functional, args.lib, quirks=bool(args.quirks), rank=rank, world=world, device=device,
                                  device_resident=None if args.device_resident < 0 else bool(args.device_resident),
-                                 eigensolver=args.eigensolver)
+                                 eigensolver=args.eigensolver, ao_mode=args.ao)
     except Exception as e:  # dft.py:149-153
         print(e)
         sys.exit(1)
@@ -118,7 +121,7 @@ def main(argv=None):
               "E_tot": res.get("E_tot"), "E_one": res.get("E_one"), "E_coul": res.get("E_coul"), "E_xc": res.get("E_xc"),
               "E_ex_hf": res.get("E_ex_hf"), "E_nuc": float(inp.E_nuc), "total_time_s": res.get("total_time"),
               "xc_ms_avg": res.get("xc_ms_avg"), "xc_ms": res.get("xc_ms"), "jk_ms": res.get("jk_ms"), "iter_ms": res.get("iter_ms"),
-              "cycle_ms": res.get("cycle_ms"), "gpu_init_s": backend.init_time, "device_resident": bool(backend.device_resident), "eigensolver": args.eigensolver,
+              "cycle_ms": res.get("cycle_ms"), "gpu_init_s": backend.init_time, "device_resident": bool(backend.device_resident), "ao": args.ao, "eigensolver": args.eigensolver,
               "eigensolver_stats": dict(backend.occ_solver.stats) if backend.occ_solver is not None else None}
     if other is not None:
         record["E_tot_other_quirks"] = other.get("E_tot"); record["other_quirks"] = 0 if args.quirks else 1

@@ -311,7 +311,7 @@ class HipBackend:
     rows of J (and, through the (i,k) view, its partial K); the all-reduce assembles them."""
 
     def __init__(self, inp, functional, lib_path=None, quirks=True, rank=0, world=1, device=None, group=None,
-                 device_resident=None, device_from=200, eigensolver="auto"):
+                 device_resident=None, device_from=200, eigensolver="auto", ao_mode="resident", ao_chunk=0):
         import torch
         from .build import library_path
         from .grid_shard import ReplicaSync, ShardedFock, eri_row_bounds, shard_bounds, vector_bounds
@@ -335,10 +335,20 @@ class HipBackend:
         self.d_w = torch.zeros(n1, dtype=f64, device=self.dev)
         d_coords[:ngrid] = torch.as_tensor(inp.grids.coords[lo:hi], dtype=f64)
         self.d_w[:ngrid] = torch.as_tensor(inp.grids.weights[lo:hi], dtype=f64)
-        self.d_ao = torch.zeros((n1, nao), dtype=f64, device=self.dev)
-        self.d_gr = torch.zeros((3, n1, nao), dtype=f64, device=self.dev) if self.functional != "LDA" else None
-        if ngrid:
-            self.solver.eval_ao(inp.shells, d_coords, ngrid, self.d_ao, self.d_gr)  # grid.py:30,38 on the device
+        # "resident" (the reference's layout, dft.py:155,172): AO values / gradients of the whole grid block stay in
+        # HBM for the run (8 ngrid nao (1 or 4) bytes; 53 GB for BASELINE config 5).  "direct": only the grid and the
+        # shell table stay; every cycle re-evaluates them chunk by chunk inside DFT_ComputeXCDirect.
+        if ao_mode not in ("resident", "direct"):
+            raise ValueError(f"ao_mode {ao_mode!r}: expected 'resident' or 'direct'")
+        self.ao_mode, self.ao_chunk, self.shells, self.d_coords = ao_mode, int(ao_chunk), inp.shells, d_coords
+        self.d_ao = self.d_gr = None
+        if ao_mode == "resident":
+            self.d_ao = torch.zeros((n1, nao), dtype=f64, device=self.dev)
+            self.d_gr = torch.zeros((3, n1, nao), dtype=f64, device=self.dev) if self.functional != "LDA" else None
+            if ngrid:
+                self.solver.eval_ao(inp.shells, d_coords, ngrid, self.d_ao, self.d_gr)  # grid.py:30,38 on the device
+        else:
+            self._d_exc = torch.zeros(1, dtype=f64, device=self.dev)
         self.d_eri = self.d_chol = self.d_cocc = None
         self.eri_rows = (0, nao * nao)
         if inp.eri is not None:
@@ -451,6 +461,9 @@ class HipBackend:
         if not self.ngrid:
             self.d_v.zero_()
             return 0.0
+        if self.ao_mode == "direct":
+            self.solver.compute_xc_direct(self.shells, self.ngrid, self.d_coords, self.d_w, self.d_dm, self.d_v, self._d_exc, self.ao_chunk)
+            return float(self._d_exc.item())                                             # device sync, like the ABI call
         exc = self.solver.compute_xc(self.ngrid, self.nao, self.d_dm, self.d_ao, self.d_w, self.d_v, self.d_gr)
         self.torch.cuda.synchronize()                                                # dft.py:205-208
         return exc

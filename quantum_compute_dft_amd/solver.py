@@ -92,6 +92,9 @@ class DFTSolverWrapper:
         L.DFT_EvalAO.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
                                  dp, ip, ip, ip, ip, dp, dp, ctypes.c_int, _u64, _u64, _u64]
         L.DFT_EvalAO.restype = ctypes.c_int
+        L.DFT_ComputeXCDirect.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                                          dp, ip, ip, ip, ip, dp, dp, ctypes.c_int, _u64, _u64, _u64, _u64, _u64, ctypes.c_longlong]
+        L.DFT_ComputeXCDirect.restype = ctypes.c_int
         L.DFT_SetOption.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]
         L.DFT_SetOption.restype = ctypes.c_int
         L.DFT_SetStream.argtypes = [ctypes.c_void_p, _u64]
@@ -169,23 +172,31 @@ class DFTSolverWrapper:
         self._check()
         return rc
 
-    def eval_ao(self, shells, d_coords, ngrid, d_ao, d_ao_grad=None):
-        """shells: a basis.ShellTable (host numpy arrays, see basis.py)."""
+    @staticmethod
+    def _shell_args(shells):
+        """(keep-alive arrays, ctypes arguments) of a basis.ShellTable for DFT_EvalAO / DFT_ComputeXCDirect."""
         import numpy as np
         dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
-        xyz = np.ascontiguousarray(shells.xyz, dtype=np.float64)
-        ls = np.ascontiguousarray(shells.l, dtype=np.int32)
-        npr = np.ascontiguousarray(shells.nprim, dtype=np.int32)
-        off = np.ascontiguousarray(shells.off, dtype=np.int32)
-        aoc = np.ascontiguousarray(shells.ao, dtype=np.int32)
-        ex = np.ascontiguousarray(shells.exp, dtype=np.float64)
-        cf = np.ascontiguousarray(shells.coef, dtype=np.float64)
-        rc = self.lib.DFT_EvalAO(
-            self.solver, int(ngrid), int(shells.nao), int(len(ls)),
-            xyz.ctypes.data_as(dp), ls.ctypes.data_as(ip), npr.ctypes.data_as(ip),
-            off.ctypes.data_as(ip), aoc.ctypes.data_as(ip), ex.ctypes.data_as(dp),
-            cf.ctypes.data_as(dp), int(len(ex)), _u64(_ptr(d_coords)), _u64(_ptr(d_ao)),
-            _u64(_ptr(d_ao_grad)))
+        arrs = [np.ascontiguousarray(shells.xyz, dtype=np.float64)] + \
+               [np.ascontiguousarray(a, dtype=np.int32) for a in (shells.l, shells.nprim, shells.off, shells.ao)] + \
+               [np.ascontiguousarray(shells.exp, dtype=np.float64), np.ascontiguousarray(shells.coef, dtype=np.float64)]
+        args = [int(shells.nao), int(len(arrs[1])), arrs[0].ctypes.data_as(dp)] + [a.ctypes.data_as(ip) for a in arrs[1:5]] + \
+               [arrs[5].ctypes.data_as(dp), arrs[6].ctypes.data_as(dp), int(len(arrs[5]))]
+        return arrs, args
+
+    def eval_ao(self, shells, d_coords, ngrid, d_ao, d_ao_grad=None):
+        """shells: a basis.ShellTable (host numpy arrays, see basis.py)."""
+        keep, args = self._shell_args(shells)
+        rc = self.lib.DFT_EvalAO(self.solver, int(ngrid), *args, _u64(_ptr(d_coords)), _u64(_ptr(d_ao)), _u64(_ptr(d_ao_grad)))
+        self._check()
+        return rc
+
+    def compute_xc_direct(self, shells, ngrid, d_coords, d_weights, d_dm, d_vxc, d_exc, chunk_points=0):
+        """AO -> rho -> XC -> Vxc without resident AO planes (DFT_ComputeXCDirect): results in d_vxc / d_exc once the
+        solver's stream has drained (asynchronous, like compute_xc_async)."""
+        keep, args = self._shell_args(shells)
+        rc = self.lib.DFT_ComputeXCDirect(self.solver, int(ngrid), *args, _u64(_ptr(d_coords)), _u64(_ptr(d_weights)),
+                                          _u64(_ptr(d_dm)), _u64(_ptr(d_vxc)), _u64(_ptr(d_exc)), int(chunk_points))
         self._check()
         return rc
 

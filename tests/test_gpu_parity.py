@@ -445,6 +445,52 @@ def test_ao_to_vxc_sweep_end_to_end(dev):
     _check(exc, d_v.cpu().numpy(), exc_ref, v_ref)
 
 
+@pytest.mark.parametrize("fn,xc_type", [("LDA", 0), ("GGA", 1), ("B3LYP", 2)])
+def test_direct_sweep_without_resident_ao_planes(dev, fn, xc_type):
+    """DFT_ComputeXCDirect (AO values re-evaluated chunk by chunk in a workspace) against the
+    resident-plane call on the same real shells and grid: equal up to the summation order over chunks, for a
+    chunk that divides the grid, a ragged last chunk, one chunk, and the automatic size; and against the oracle."""
+    from quantum_compute_dft_amd import basis, grid_gen, inputs
+    syms, xyz = basis.parse_xyz(os.path.join(inputs.DATA_DIR, "H2O.xyz"))
+    sh = basis.build_shells(syms, xyz, "def2-svp")
+    grids = grid_gen.Grids(syms, xyz, level=1)
+    ngrid, nao = grids.size, sh.nao
+    rng = np.random.default_rng(5)
+    C = rng.normal(0, 0.4, (nao, 5)); dm = 2.0 * C @ C.T
+    w = _solver(xc_type)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    d_c, d_w, d_dm = t(grids.coords), t(grids.weights), t(dm)
+    d_ao = torch.zeros((ngrid, nao), dtype=torch.float64, device=dev)
+    d_gr = torch.zeros((3, ngrid, nao), dtype=torch.float64, device=dev)
+    w.eval_ao(sh, d_c, ngrid, d_ao, d_gr)
+    d_v = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
+    exc0 = w.compute_xc(ngrid, nao, d_dm, d_ao, d_w, d_v, d_gr if xc_type else None)
+    v0 = d_v.cpu().numpy()
+    exc_ref, v_ref = oracle.compute_xc(xc_type, dm, d_ao.cpu().numpy(), grids.weights, d_gr.cpu().numpy() if xc_type else None)
+    d_e = torch.zeros(1, dtype=torch.float64, device=dev)
+    for chunk in (256, 1000, ngrid, 10 * ngrid, 0):
+        d_v.fill_(7.0); d_e.fill_(7.0)                       # outputs are overwritten, not accumulated into
+        w.compute_xc_direct(sh, ngrid, d_c, d_w, d_dm, d_v, d_e, chunk)
+        torch.cuda.synchronize()
+        v, exc = d_v.cpu().numpy(), float(d_e.item())
+        assert exc == pytest.approx(exc0, rel=1e-12), chunk
+        assert np.abs(v - v0).max() <= 1e-12 * np.abs(v0).max(), chunk
+        _check(exc, v, exc_ref, v_ref)
+    with pytest.raises(RuntimeError):
+        w.compute_xc_direct(sh, 0, d_c, d_w, d_dm, d_v, d_e)
+
+
+def test_scf_in_direct_ao_mode_matches_the_resident_mode(dev):
+    from quantum_compute_dft_amd import inputs, scf
+    inp = inputs.build("H2O", "def2-svp", 3, verbose=False)
+    r0 = scf.run_scf(inp, scf.HipBackend(inp, "GGA"), "GGA", log=None)
+    be = scf.HipBackend(inp, "GGA", ao_mode="direct", ao_chunk=8192)
+    assert be.d_ao is None and be.d_gr is None
+    r1 = scf.run_scf(inp, be, "GGA", log=None)
+    assert r0["converged"] and r1["converged"] and r0["cycles"] == r1["cycles"]
+    assert r1["E_tot"] == pytest.approx(r0["E_tot"], abs=1e-10)
+
+
 def test_error_reporting_on_bad_arguments(dev):
     w = _solver(1)
     d = torch.zeros(4, dtype=torch.float64, device=dev)
