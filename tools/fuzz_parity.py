@@ -13,7 +13,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
 t_end = time.time() + budget
-n_xc = n_jk = n_cd = n_ao = 0
+n_xc = n_jk = n_cd = n_ao = n_direct = 0
 worst = {"xc_e": 0.0, "xc_v": 0.0, "jk": 0.0, "cd": 0.0, "ao": 0.0}
 names = ["LDA", "GGA", "B3LYP"]
 while time.time() < t_end:
@@ -91,4 +91,17 @@ while time.time() < t_end:
         if deriv: err = max(err, np.abs(d_gr.cpu().numpy() - ref[1]).max() / max(1.0, np.abs(ref[1]).max()))
         worst["ao"] = max(worst["ao"], err); n_ao += 1
         assert err < 1e-12, ("AO", bname, natm, ngrid, deriv, sh.nao, err)
-print(f"fuzz ok: {n_xc} XC sweeps, {n_jk} dense J/K, {n_cd} factorised J/K, {n_ao} AO evaluations; worst relative errors {worst}")
+        if deriv:   # the direct sweep (planes re-evaluated chunk by chunk) against the resident-plane call on the same shells
+            xc = int(rng.integers(0, 3)); nao = sh.nao
+            C = rng.normal(0, 0.4, (nao, max(1, nao // 4))); dm = 2.0 * C @ C.T
+            w = np.abs(rng.normal(0.1, 0.05, ngrid))
+            sx = q.DFTSolverWrapper(q.library_path(), names[xc])
+            d_v, d_v2, d_e = (torch.full(sz, 5.0, dtype=torch.float64, device=dev) for sz in ((nao, nao), (nao, nao), (1,)))
+            e0 = sx.compute_xc(ngrid, nao, t(dm), d_ao, t(w), d_v, d_gr if xc else None)
+            sx.compute_xc_direct(sh, ngrid, t(coords), t(w), t(dm), d_v2, d_e, int(rng.choice([0, 1, 16, 256, 1024, 5000])))
+            torch.cuda.synchronize()
+            ed = abs(float(d_e.item()) - e0) / max(1e-300, abs(e0))
+            vd = float((d_v2 - d_v).abs().max()) / max(1e-300, float(d_v.abs().max()))
+            worst["direct"] = max(worst.get("direct", 0.0), ed, vd); n_direct += 1
+            assert ed < 1e-11 and vd < 1e-10, ("direct", bname, natm, ngrid, xc, ed, vd)
+print(f"fuzz ok: {n_xc} XC sweeps, {n_jk} dense J/K, {n_cd} factorised J/K, {n_ao} AO evaluations, {n_direct} direct sweeps; worst relative errors {worst}")
