@@ -23,6 +23,8 @@ Output = ONE JSON line on rank 0 (metric grid-points/s).  `roofline` is the WHOL
          Benzene/def2-SVP's real shells and level-3 grid; `scf_iteration*` one SCF cycle at the Benzene
          GGA and Anthracene B3LYP shapes (synthetic operands, eigh(F, S) every cycle as the reference's loop);
          `scf_benzene_real` the driver's whole SCF on the real Benzene PBE/def2-SVP (energy as checksum); `k_build` the factorised exact exchange on the fp64 matrix cores.
+The headline is measured first and its line is complete before any extra leg starts; the legs run under a watchdog
+         (`--legs-seconds`) and a leg that fails or hangs only costs its own member (`legs_note` says so).
 """
 import argparse
 import glob
@@ -501,6 +503,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-k-build", action="store_true", help="skip the factorised exact-exchange (fp64 MFMA) measurement")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip ao_sweep / scf_iteration / strong_config5 (kernel iteration runs)")
+    ap.add_argument("--legs-seconds", type=float, default=420.0,
+                    help="watchdog for everything after the headline measurement: the JSON line is printed with the legs finished by then")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo only to rehearse N>1 on a single card")
     args = ap.parse_args()
@@ -612,16 +616,8 @@ def main():
         solver.set_option("profile", 0)
         kern = {k: float(np.mean(v)) for k, v in acc.items()}
 
-    strong5 = scf_sh = None
-    if not strong and not args.no_extra_legs:            # every rank takes part (collective inside)
-        del ao, gr
-        ao = gr = None
-        torch.cuda.empty_cache()
-        strong5 = strong_leg(lib_path, dev, dist, args.backend, world, rank, "c33_b3lyp_def2svp")
-        scf_sh = scf_sharded_leg(lib_path, dev, dist, args.backend, world, rank) if world > 1 else None
-        if rank == 0 and world == 1:
-            dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)   # the same inputs again for the legs below
-
+    # ---- the headline line is complete here; everything below only adds members to it ---------------------------
+    line = None
     if rank == 0:
         t_step = dt / args.steps
         # whole call against SURVEY 8(d): B = ngrid(8 nao c + 8) + 16 nao^2, F = 4 ngrid nao^2 + (2c + 8[c=4]) ngrid nao
@@ -656,31 +652,72 @@ def main():
                        "sharding": "grid points" + ("" if world == 1 else f" x{world}, RCCL all-reduce of Vxc|Exc ({8 * (nao * nao + 1)} B)")},
             "roofline": roof, "kernels_ms": kern, "exc": exc,
         }
-        if strong5 is not None:
-            line["strong_config5"] = strong5
-            if scf_sh is not None:
-                line["scf_iteration_anthracene_sharded"] = scf_sh
-        if world == 1 and not strong and not args.no_extra_legs:
-            line["ao_sweep"] = ao_sweep_leg(lib_path, dev)
-            line["scf_iteration"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev)
-            line["scf_iteration_factorised_j"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, eri="cholesky")
-            line["scf_benzene_real"] = scf_real_leg(lib_path, dev)
+
+    # The extra legs must never cost the headline: a watchdog thread ends the process after `args.legs_seconds` -- rank 0
+    # printing the line with whatever legs have finished -- and a leg that raises is recorded and ends the extra legs
+    # (with N > 1 the ranks' collectives would be out of step after it).  The thread runs while the main thread waits
+    # inside HIP / RCCL (torch drops the GIL there).
+    import threading
+    printed = threading.Lock()
+
+    def emit(note=None):
+        if not printed.acquire(blocking=False):
+            return
+        if line is not None:
+            if note:
+                line["legs_note"] = note
+            print(json.dumps(line), flush=True)
+
+    def expire():
+        emit(f"extra legs cut off after {args.legs_seconds:.0f} s: members present are complete, the others are missing")
+        os._exit(0)
+
+    dog = threading.Timer(args.legs_seconds, expire)
+    dog.daemon = True
+    dog.start()
+    note = None
+    try:
+        if not strong and not args.no_extra_legs:            # every rank takes part (collectives inside)
             del ao, gr
+            ao = gr = None
             torch.cuda.empty_cache()
-            xa, na, ga = WORKLOADS["anthracene_b3lyp_def2tzvp"]
-            dm_a, ao_a, gr_a, w_a = synth(ga, na, True, dev, SEED)
-            line["scf_iteration_anthracene"] = scf_iteration_ms(q.DFTSolverWrapper(lib_path, xa), xa, na, ga, dm_a, ao_a, gr_a, w_a, dev, iters=7)
-            del ao_a, gr_a
-            torch.cuda.empty_cache()
-            dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)
+            strong5 = strong_leg(lib_path, dev, dist, args.backend, world, rank, "c33_b3lyp_def2svp")
+            if line is not None:
+                line["strong_config5"] = strong5
+            if world > 1:
+                scf_sh = scf_sharded_leg(lib_path, dev, dist, args.backend, world, rank)
+                if line is not None:
+                    line["scf_iteration_anthracene_sharded"] = scf_sh
+            if world == 1:
+                dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)   # the same inputs again for the legs below
+                line["ao_sweep"] = ao_sweep_leg(lib_path, dev)
+                line["scf_iteration"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev)
+                line["scf_iteration_factorised_j"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, eri="cholesky")
+                line["scf_benzene_real"] = scf_real_leg(lib_path, dev)
+                del ao, gr
+                torch.cuda.empty_cache()
+                xa, na, ga = WORKLOADS["anthracene_b3lyp_def2tzvp"]
+                dm_a, ao_a, gr_a, w_a = synth(ga, na, True, dev, SEED)
+                line["scf_iteration_anthracene"] = scf_iteration_ms(q.DFTSolverWrapper(lib_path, xa), xa, na, ga, dm_a, ao_a, gr_a, w_a, dev, iters=7)
+                del ao_a, gr_a
+                torch.cuda.empty_cache()
+                dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)
         if world == 1 and not args.no_k_build:
             line["k_build"] = k_build_mfma(lib_path, dev)
         if world == 1 and not args.no_cpu_baseline:
+            if ao is None:
+                dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)
             line["cpu_baseline"] = cpu_baseline(xc, dm, ao, gr, w, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
+    except Exception as e:   # noqa: BLE001 -- whatever a leg raises, the measured headline is still printed
+        note = f"an extra leg failed ({type(e).__name__}: {e}); members present are complete"
+    dog.cancel()
+    emit(note)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        if note is None:
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            os._exit(0)    # the ranks may be out of step: no further collective
 
 
 if __name__ == "__main__":
