@@ -22,7 +22,8 @@ Output = ONE JSON line on rank 0 (metric grid-points/s).  `roofline` is the WHOL
          bounded slice of the same inputs (N=1, rank 0 only); `ao_sweep` the AO-on-grid kernel on
          Benzene/def2-SVP's real shells and level-3 grid; `scf_iteration*` one SCF cycle at the Benzene
          GGA and Anthracene B3LYP shapes (synthetic operands, eigh(F, S) every cycle as the reference's loop);
-         `scf_benzene_real` the driver's whole SCF on the real Benzene PBE/def2-SVP (energy as checksum); `k_build` the factorised exact exchange on the fp64 matrix cores.
+         `scf_benzene_real` / `scf_anthracene_def2svp_real` the driver's whole SCF on the real molecules (energy as checksum; the
+         second one sharded over the N ranks); `k_build` the factorised exact exchange on the fp64 matrix cores.
 The headline is measured first and its line is complete before any extra leg starts; the legs run under a watchdog
          (`--legs-seconds`) and a leg that fails or hangs only costs its own member (`legs_note` says so).
 """
@@ -347,6 +348,31 @@ def scf_real_leg(lib_path, dev, molecule="Benzene", functional="GGA", basis_name
                                     "eigensolver": dict(be.occ_solver.stats) if be.occ_solver is not None else "eigh(F, S) every cycle"}
             del be
     del inp, inp_cd
+    torch.cuda.empty_cache()
+    return out
+
+
+def scf_real_sharded_leg(lib_path, dev, world, rank, molecule="Anthracene", functional="B3LYP", basis_name="def2-svp", tol=1e-8):
+    """The BASELINE metric "ms/SCF-iter (Anthracene B3LYP)" through the driver's own path on N GPUs: real shells,
+    level-3 grid and Cholesky vectors of the ERI (every rank builds the inputs, keeps its grid block and its slice of
+    the vectors: scf.HipBackend), the loop of scf.run_scf with rank 0 authoritative -- ONE all-reduce of
+    [Vxc | J | K | Exc] and ONE broadcast of [dm | cocc | scalars] per cycle.  def2-SVP (nao 246): the def2-TZVP-shaped
+    basis of config 3 needs 12 s of host integrals per rank, too long for a bench leg (its cycle: profiles/r02_scf_*).
+    The converged energy is the checksum (-539.14207342 Ha on one GPU)."""
+    from quantum_compute_dft_amd import inputs, scf
+    t0 = time.perf_counter()
+    inp = inputs.build(molecule, basis_name, 3, device=dev, verbose=False, eri_mode="cholesky", chol_tol=tol)
+    t_build = time.perf_counter() - t0
+    be = scf.HipBackend(inp, functional, lib_path, rank=rank, world=world, device=dev)
+    r = scf.run_scf(inp, be, functional, log=None)
+    out = {"workload": f"{molecule} {functional}/{basis_name}: nao {inp.shells.nao}, {inp.grids.size} grid points, {inp.chol.shape[0]} Cholesky vectors "
+                       f"({tol:g}), sharded over {world} GPU(s); inputs built on every rank in {t_build:.1f} s (not timed)",
+           "scaling": "strong", "ms_per_cycle": r["iter_ms"], "xc_ms": r["xc_ms"], "jk_ms": r["jk_ms"], "cycles": r["cycles"],
+           "converged": bool(r["converged"]), "E_tot": r["E_tot"], "total_ms": 1e3 * r["total_time"],
+           "device_resident": bool(be.device_resident),
+           "eigensolver": dict(be.occ_solver.stats) if be.occ_solver is not None else "eigh(F, S) every cycle",
+           "statistic": "rank 0's median per cycle after the first (every cycle ends in a collective, so all ranks keep its pace)"}
+    del be, inp
     torch.cuda.empty_cache()
     return out
 
@@ -688,6 +714,9 @@ def main():
                 scf_sh = scf_sharded_leg(lib_path, dev, dist, args.backend, world, rank)
                 if line is not None:
                     line["scf_iteration_anthracene_sharded"] = scf_sh
+            scf_an = scf_real_sharded_leg(lib_path, dev, world, rank)
+            if line is not None:
+                line["scf_anthracene_def2svp_real"] = scf_an
             if world == 1:
                 dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)   # the same inputs again for the legs below
                 line["ao_sweep"] = ao_sweep_leg(lib_path, dev)
