@@ -13,6 +13,12 @@ def host_cpu_share(cap=16):
             n = min(n, max(1, int(int(q) / int(per))))
     except (OSError, ValueError):
         pass
+    # ranks of one node (torch.distributed.run exports LOCAL_WORLD_SIZE) share that allowance: without the division
+    # N ranks start N x share threads on the same cores (integrals, LAPACK) and slow each other down
+    try:
+        n = max(1, n // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+    except ValueError:
+        pass
     return max(1, min(n, cap))
 
 
