@@ -1,7 +1,7 @@
 """Randomised parity sweep on the GPU: DFT_ComputeXC (all functionals, all kernel paths), dense and factorised
-J/K, AO evaluation -- each against the oracle on random sizes.  usage: fuzz_parity.py [seconds] [seed]"""
+J/K, AO evaluation -- each against the oracle on random sizes.  usage: python tests/fuzz_parity.py [seconds] [seed]  (a checker like the tests next to it: the only places the oracle is used from)"""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os; _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'tests'))
 import oracle
 import quantum_compute_dft_amd as q
 from quantum_compute_dft_amd.hostinfo import blas_threads

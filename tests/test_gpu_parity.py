@@ -206,7 +206,7 @@ def test_low_density_cutoff_points(dev, xc_type):
 
 
 def test_conditioning_aware_bound_on_ill_conditioned_small_bases(dev):
-    """The randomised sweep (tools/fuzz_parity.py, profiles/r01_fuzz_parity.txt) found Vxc differences up to 7e-8
+    """The randomised sweep (tests/fuzz_parity.py, profiles/r01_fuzz_parity.txt) found Vxc differences up to 7e-8
     relative for B3LYP at nao 2-3: unphysical low-density / high-gradient points of the synthetic grid where LYP is
     ill-conditioned in rho.  The bound that holds on ANY input is conditioning-aware: the distance to the oracle
     may not exceed a fixed multiple of the oracle's own response to last-bit perturbations of its inputs (plus the
