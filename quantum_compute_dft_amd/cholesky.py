@@ -60,8 +60,9 @@ def _cholesky_eri_device(shells, tol, span, max_vectors, screen, verbose, device
             nq = nc * nd
             qidx_h = ((c0 + np.arange(nc))[:, None] * n + (d0 + np.arange(nd))[None, :]).reshape(-1)
             qidx = torch.as_tensor(qidx_h, device=dev)
-            eri.cols(C, D, screen, out=stage_np[:nq])
-            res = stage[:nq].to(dev, non_blocking=True)
+            eri.cols(C, D, screen, out=stage_np[:nq], lower_only=True)     # the host writes i >= j only (integrals.c)
+            low = stage[:nq].to(dev, non_blocking=True).view(nq, n, n)
+            res = (torch.tril(low) + torch.tril(low, -1).transpose(1, 2)).reshape(nq, n2)   # ... and the device mirrors
             if k:
                 res -= L[:k, qidx].T @ L[:k]
             floor = max(tol, span * dmax)

@@ -57,6 +57,8 @@ def _load():
         L.qc_eri_diag.argtypes = [ctypes.c_void_p, dp]
         L.qc_eri_cols.restype = ctypes.c_int
         L.qc_eri_cols.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, dp]
+        L.qc_eri_cols2.restype = ctypes.c_int
+        L.qc_eri_cols2.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, ctypes.c_int]
         L.qc_set_threads.restype = None
         L.qc_set_threads.argtypes = [ctypes.c_int]
         from .hostinfo import host_cpu_share
@@ -135,15 +137,16 @@ class EriColumns:
         _load().qc_eri_diag(self._h, d.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
         return d
 
-    def cols(self, C, D, screen=1e-14, out=None):
+    def cols(self, C, D, screen=1e-14, out=None, lower_only=False):
         """(nfC*nfD, nao, nao): entry [k*nfD + l] is the symmetric matrix (..|kl).  `out`: a C-contiguous float64
-        buffer of nfC*nfD*nao^2 elements to write into (e.g. pinned memory), returned reshaped."""
+        buffer of nfC*nfD*nao^2 elements to write into (e.g. pinned memory), returned reshaped.  `lower_only`: only the
+        elements [i][j] with i >= j are written (the rest stay zero); the caller mirrors them."""
         nf = (2 * int(self.shells.l[C]) + 1) * (2 * int(self.shells.l[D]) + 1)
         if out is None:
             out = np.empty((nf, self.nao, self.nao))
         else:
             assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"] and out.size == nf * self.nao * self.nao
-        rc = _load().qc_eri_cols(self._h, int(C), int(D), float(screen), out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        rc = _load().qc_eri_cols2(self._h, int(C), int(D), float(screen), out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(bool(lower_only)))
         if rc != 0:
             raise RuntimeError("qc_eri_cols failed (diag() must be called first)")
         return out.reshape(nf, self.nao, self.nao)

@@ -50,8 +50,9 @@ def test_occupied_rotation_reproduces_the_exact_loop(mol, bname, fn, level):
     be.occ_solver = scf.OccupiedRotation(inp.S, inp.nocc)
     r1 = scf.run_scf(inp, be, fn, **kw)
     # converged 100x tighter than the driver does: the last cycles move dm by 1e-9, where a 1e-10 difference in
-    # the occupied space decides a cycle earlier or later
-    assert r0["converged"] and r1["converged"] and abs(r1["cycles"] - r0["cycles"]) <= 3
+    # the occupied space decides a cycle earlier or later (a 1e-16 change of the integrals moved H2O/GGA from 15/17 to
+    # 15/19 cycles): the count is only bounded loosely here, and to one cycle at the driver's thresholds below
+    assert r0["converged"] and r1["converged"] and abs(r1["cycles"] - r0["cycles"]) <= 5
     assert r1["E_tot"] == pytest.approx(r0["E_tot"], abs=1e-9)
     assert np.abs(r1["dm"] - r0["dm"]).max() < 1e-7
     st = be.occ_solver.stats
