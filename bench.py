@@ -20,8 +20,10 @@ Output = ONE JSON line on rank 0 (metric grid-points/s).  `roofline` is the WHOL
          8(d)'s algorithmic bytes/flops (its `dominant_kernel` member is the single-kernel figure, HIP
          events on the solver's stream); `cpu_baseline` is the prebuilt OpenMP CPU oracle timed on a
          bounded slice of the same inputs (N=1, rank 0 only); `ao_sweep` the AO-on-grid kernel on
-         Benzene/def2-SVP's real shells and level-3 grid; `scf_iteration*` one SCF cycle at the Benzene
-         GGA and Anthracene B3LYP shapes (synthetic operands, eigh(F, S) every cycle as the reference's loop);
+         Benzene/def2-SVP's real shells and level-3 grid; `scf_iteration`, `scf_iteration_factorised_j`,
+         `scf_iteration_anthracene` = ms per SCF cycle of the driver's own loop on the real Benzene PBE/def2-SVP and
+         Anthracene B3LYP/def2-TZVP-shaped basis (converged energies as checksums); `scf_iteration*_synthetic` the same
+         loop body on synthetic operands with eigh(F, S) every cycle (the reference's loop; round 1's legs);
          `scf_benzene_real` / `scf_anthracene_def2svp_real` the driver's whole SCF on the real molecules (energy as checksum; the
          second one sharded over the N ranks); `k_build` the factorised exact exchange on the fp64 matrix cores.
 The headline is measured first and its line is complete before any extra leg starts; the legs run under a watchdog
@@ -720,16 +722,30 @@ def main():
             if world == 1:
                 dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)   # the same inputs again for the legs below
                 line["ao_sweep"] = ao_sweep_leg(lib_path, dev)
-                line["scf_iteration"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev)
-                line["scf_iteration_factorised_j"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, eri="cholesky")
-                line["scf_benzene_real"] = scf_real_leg(lib_path, dev)
+                # ms/SCF-iter of the BASELINE metric = the driver's own loop on the real molecules (energies as checksums)
+                real = scf_real_leg(lib_path, dev)
+                line["scf_benzene_real"] = real
+                for key, src, what in (("scf_iteration", "dense_eri_auto", "dense ERI (the reference's formulation, dft.py:166,203)"),
+                                       ("scf_iteration_factorised_j", "factorised_j_auto", "factorised J (Cholesky vectors, 1e-8)")):
+                    r = real[src]
+                    line[key] = {"ms": r["ms_per_cycle"], "workload": real["workload"] + "; " + what, "statistic": real["statistic"],
+                                 "parts_ms": {"xc": r["xc_ms"], "jk": r["jk_ms"], "host_eigen_diis_fock_transfers": r["ms_per_cycle"] - r["xc_ms"] - r["jk_ms"]},
+                                 "cycles": r["cycles"], "converged": r["converged"], "E_tot": r["E_tot"], "eigensolver": r["eigensolver"],
+                                 "eigh_every_cycle_ms": real[src.replace("_auto", "_exact")]["ms_per_cycle"]}
+                # the same loop body with synthetic operands and eigh(F, S) EVERY cycle (round 1's legs, kept for comparison)
+                line["scf_iteration_synthetic"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev)
+                line["scf_iteration_synthetic_factorised_j"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, eri="cholesky")
                 del ao, gr
                 torch.cuda.empty_cache()
                 xa, na, ga = WORKLOADS["anthracene_b3lyp_def2tzvp"]
                 dm_a, ao_a, gr_a, w_a = synth(ga, na, True, dev, SEED)
-                line["scf_iteration_anthracene"] = scf_iteration_ms(q.DFTSolverWrapper(lib_path, xa), xa, na, ga, dm_a, ao_a, gr_a, w_a, dev, iters=7)
+                line["scf_iteration_anthracene_synthetic"] = scf_iteration_ms(q.DFTSolverWrapper(lib_path, xa), xa, na, ga, dm_a, ao_a, gr_a, w_a, dev, iters=7)
                 del ao_a, gr_a
                 torch.cuda.empty_cache()
+                # BASELINE config 3 through the driver: Anthracene B3LYP in the def2-TZVP-shaped basis (nao 494; ~12 s of host
+                # integrals for its Cholesky vectors, hence last among the SCF legs)
+                an = scf_real_sharded_leg(lib_path, dev, 1, 0, basis_name="def2-tzvp", tol=1e-7)
+                line["scf_iteration_anthracene"] = dict(an, ms=an["ms_per_cycle"])
                 dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)
         if world == 1 and not args.no_k_build:
             line["k_build"] = k_build_mfma(lib_path, dev)
