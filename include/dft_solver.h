@@ -13,10 +13,11 @@
  *   dm (nao,nao) | ao (ngrid,nao) | ao_grad (3,ngrid,nao) planar | weights (ngrid)
  *   vxc (nao,nao) overwritten | eri (nao^2,nao^2) | J, K (nao,nao) overwritten.
  * Work is enqueued on the solver's stream (default: the null stream, like the
- * reference); DFT_ComputeXC returns Exc once the call's last kernel has published
- * it: every consumer on the solver's stream (the reference's pattern, dft.py:211)
- * is ordered behind the call; option "strict_sync" = 1 additionally waits until
- * the stream reports complete (consumers on other streams / mapped host reads).
+ * reference); DFT_ComputeXC returns Exc once the call's last kernel -- a one-block
+ * finishing kernel that stream order starts after every other kernel of the call
+ * has completed -- has published it: on return Vxc is complete for consumers on
+ * any stream, as after the reference's blocking copy (dft_solver.cu:575-582).
+ * (Option "fuse_finish" = 1 trades that for one launch less: see DFT_SetOption.)
  * Every entry point runs on the device that was current at DFT_CreateSolver.
  * No function throws or aborts; failures print one line to stderr, are
  * retrievable with DFT_GetLastError(), and make DFT_ComputeXC return NaN.
@@ -77,6 +78,34 @@ double DFT_ComputeXC64(XCSolver *solver, long long ngrid, int nao,
                        unsigned long long d_ao_grad_ptr,
                        unsigned long long d_weights_ptr,
                        unsigned long long d_vxc_ptr);
+
+/* DFT_ComputeXC with the OCCUPIED ORBITALS of the density: d_cocc_ptr (nao, nocc) f64 C-order with
+ * dm = cocc . cocc^T (occupation folded in: sqrt(2) C_occ for the closed-shell dm of dft.py:181-182; the
+ * same contract as DFT_ComputeJKFactorized).  Same results as DFT_ComputeXC(dm) -- same Exc, same Vxc
+ * conventions per solver type -- but the density step runs as Y = AO . cocc, rho = rowsum(Y^2),
+ * X = Y . cocc^T, grad rho = 2 rowsum(X * dAO): 4 nao nocc flops per grid point on the matrix cores instead
+ * of the 2 nao^2 of the reference's contraction with the full matrix (dft_solver.cu:294-307, 346-380).
+ * d_dm_ptr may be 0; where the occupied form does not do fewer matrix instructions (nocc close to nao/2:
+ * minimal basis sets) the library takes the dm path, with the caller's dm if given, else with cocc . cocc^T
+ * formed on the device.  A dm that is NOT cocc . cocc^T is the caller's error (the result then follows cocc
+ * or dm depending on the path taken).  Returns Exc like DFT_ComputeXC. */
+double DFT_ComputeXCOcc(XCSolver *solver, long long ngrid, int nao, int nocc,
+                        unsigned long long d_cocc_ptr,
+                        unsigned long long d_dm_ptr,
+                        unsigned long long d_ao_ptr,
+                        unsigned long long d_ao_grad_ptr,
+                        unsigned long long d_weights_ptr,
+                        unsigned long long d_vxc_ptr);
+
+/* Asynchronous form of DFT_ComputeXCOcc (see DFT_ComputeXCAsync). */
+int DFT_ComputeXCOccAsync(XCSolver *solver, long long ngrid, int nao, int nocc,
+                          unsigned long long d_cocc_ptr,
+                          unsigned long long d_dm_ptr,
+                          unsigned long long d_ao_ptr,
+                          unsigned long long d_ao_grad_ptr,
+                          unsigned long long d_weights_ptr,
+                          unsigned long long d_vxc_ptr,
+                          unsigned long long d_exc_ptr);
 
 /* Asynchronous form: Exc is written to the device double at d_exc_ptr; no
  * host synchronisation.  Returns 0 on success. */
@@ -178,8 +207,11 @@ int DFT_ComputeXCDirect(XCSolver *solver, long long ngrid, int nao, int nshell,
  * (1 = record per-kernel HIP events for DFT_GetTimings), "ksplit" (grid chunks
  * of the generic Vxc contraction; 0 = auto), "spin_wait" (1, default: the host
  * polls the host-mapped Exc word written by the last kernel instead of sleeping
- * in hipStreamSynchronize), "strict_sync" (0, default; 1 = DFT_ComputeXC also waits
- * for the stream to report complete before returning), "ao_pt" (grid points per workgroup of DFT_EvalAO:
+ * in hipStreamSynchronize), "fuse_finish" (0, default; 1 = the Vxc reduce kernel publishes Exc itself, one launch
+ * fewer: DFT_ComputeXC may then return while that kernel's last blocks still store Vxc, which only
+ * consumers on the solver's own stream are ordered behind), "strict_sync" (with fuse_finish = 1: 1 =
+ * DFT_ComputeXC also waits for the stream to report complete before returning), "occ" (DFT_ComputeXCOcc:
+ * 0 = auto, 1 = always the occupied-orbital density step, 2 = never), "ao_pt" (grid points per workgroup of DFT_EvalAO:
  * 8, 16, or 0 = auto), "rho_rows" (grid rows per workgroup of the large-basis
  * density kernel: 64, default, or 128).  Returns 0 if the key is known. */
 int DFT_SetOption(XCSolver *solver, const char *key, double value);

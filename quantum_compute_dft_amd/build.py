@@ -24,14 +24,14 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdft.so")
 STAMP_PATH = LIB_PATH + ".srchash"
-SOURCES = ["dft_api.hip"]
+SOURCES = ["dft_api.hip", "xc_occ.hip"]   # one object each, compiled in parallel, linked into libdft.so
 HEADERS = ["xc_functionals.hpp", "xc_kernels.hpp", "xc_ws_kernels.hpp", "xc_ws16_kernels.hpp", "xc_big_kernels.hpp",
-           "jk_kernels.hpp", "ao_kernels.hpp", "cd_kernels.hpp", "device_util.hpp",
+           "xc_occ_kernels.hpp", "xc_occ_launch.hpp", "jk_kernels.hpp", "ao_kernels.hpp", "cd_kernels.hpp", "device_util.hpp",
            os.path.join("..", "..", "include", "dft_solver.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950's register file is unified);
 # without it hipcc 7.2 can wrap every MFMA group of a loop in v_accvgpr_write/read copy storms
 # (measured on the fp64 probe: 35 -> 75 TFLOP/s, profiles/r01_mfma_f64_probe2.txt).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wall", "-Wno-unused-function"]
 
 
@@ -92,10 +92,25 @@ def build_library(force=False, verbose=False):
             return LIB_PATH
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         tmp = LIB_PATH + f".tmp{os.getpid()}"
-        cmd = [hipcc] + FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", tmp]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True, env=compile_env())
+        objs = [os.path.join(LIB_DIR, f"{os.path.splitext(f)[0]}.tmp{os.getpid()}.o") for f in SOURCES]
+        cmds = [[hipcc] + FLAGS + ["-c", os.path.join(CSRC, f), "-o", o] for f, o in zip(SOURCES, objs)]
+        try:
+            procs = []
+            for cmd in cmds:                      # the translation units compile side by side
+                if verbose:
+                    print(" ".join(cmd))
+                procs.append(subprocess.Popen(cmd, env=compile_env()))
+            rcs = [p.wait() for p in procs]
+            if any(rcs):
+                raise subprocess.CalledProcessError(max(rcs), cmds[rcs.index(max(rcs))])
+            link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
+            if verbose:
+                print(" ".join(link))
+            subprocess.run(link, check=True, env=compile_env())
+        finally:
+            for o in objs:
+                if os.path.exists(o):
+                    os.remove(o)
         os.replace(tmp, LIB_PATH)               # atomic: a concurrent loader sees the old or the new file
         with open(STAMP_PATH, "w") as fh:
             fh.write(want + "\n")

@@ -25,6 +25,7 @@
 #include "xc_ws_kernels.hpp"
 #include "xc_ws16_kernels.hpp"
 #include "xc_kernels.hpp"
+#include "xc_occ_launch.hpp"
 
 using namespace qcdft;
 
@@ -54,13 +55,20 @@ struct XCSolver {
     int profile = 0;
     int ksplit = 0;
     int ao_pt = 0; // grid points per workgroup of the AO kernel: 0 auto, 8 or 16
-    int fuse_finish = 1; // the Vxc reduce kernel's last block also finishes Exc (one launch fewer)
+    // 0 (default): Exc is finished by a one-block kernel of its own BEHIND the Vxc reduce -- stream order puts it after
+    // every store of the call, so the host-mapped word means "the whole call has completed" for any consumer (other
+    // streams, mapped host reads): the reference's contract (blocking copy + cudaFree, dft_solver.cu:575-582).
+    // 1 (opt-in): the reduce kernel's highest-index block finishes Exc itself (one launch and ~1.5 us fewer); the word
+    // then only orders consumers on the solver's own stream.
+    int fuse_finish = 0;
     int rho_rows = 64; // grid rows per workgroup of the large-basis rho kernel: 64 (two workgroups per CU) or 128
     int sweep_order = 2; // bit 0: rho kernel walks the grid backwards, bit 1: Vxc kernel does (default: rho forward, Vxc backward)
     int dbg = 0;       // diagnostics only (ablations of the sixteen-wave kernels: 1 = no plane loads, 2 = no MFMAs)
     int ws_waves = 0;  // wave-specialised kernels (nao <= 128): 0 auto, 8 = 4+4 waves per workgroup, 16 = 8+8
+    int occ = 0;       // DFT_ComputeXCOcc: 0 auto (occupied-orbital density step where it does fewer MFMAs), 1 always, 2 never
+    int used_occ = 0;  // what the last sweep did (DFT_GetTimings names say so too)
     // workspace
-    DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells, msym, cdy, cdc, cdv, ao_ws, vtmp;
+    DevBuf dsym, rho, sigma, grad, coef, partial, slabs, exc, jpart, kpart, shells, msym, cdy, cdc, cdv, ao_ws, vtmp, occ_cp, occ_dm;
     int spin_wait = 1; // poll the host-mapped Exc instead of sleeping in hipStreamSynchronize
     int strict_sync = 0; // 1: after the Exc word, also poll the stream until it reports complete (+8-10 us per call)
     double *h_exc = nullptr;   // pinned, host-mapped: the reduce kernel writes Exc here
@@ -170,8 +178,11 @@ int auto_ksplit(const XCSolver *s, long ngrid, int nblk)
     }
 
 // The sweep: everything on s->stream, Exc left in s->exc (device).
+// `cocc` (nao, nocc) with dm = cocc cocc^T switches the density step to the occupied-orbital form where that
+// pays (xc_occ_kernels.hpp); `dm` may then be null.
 bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *ao,
-              const double *ao_grad, const double *w, double *vxc, bool want_host_exc)
+              const double *ao_grad, const double *w, double *vxc, bool want_host_exc,
+              const double *cocc = nullptr, int nocc = 0)
 {
     s->last_error.clear();
     s->n_timed = 0;
@@ -187,6 +198,29 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     if (gga && !ao_grad) {
         set_error(s, "ao_grad pointer is null for a gradient-corrected functional");
         return false;
+    }
+    if (!dm && !cocc) {
+        set_error(s, "neither a density matrix nor occupied orbitals were given");
+        return false;
+    }
+    if (cocc && nocc <= 0) {
+        set_error(s, "occupied orbitals given with nocc=%d", nocc);
+        return false;
+    }
+    // Occupied-orbital density step: 16 nch nocc_tiles MFMAs per 16 grid rows (8 for LDA) against 4 NT^2 through the
+    // full matrix; taken when it does clearly fewer (the two kernels run at similar matrix-pipe efficiency), on the
+    // production path only.
+    OccPlan oplan;
+    bool use_occ = false;
+    if (cocc && s->path == 0 && s->occ != 2) {
+        oplan = occ_plan(nao, nocc, gga);
+        use_occ = s->occ == 1 || oplan.mfma_occ <= 0.85 * oplan.mfma_full;
+    }
+    s->used_occ = use_occ;
+    if (!use_occ && !dm) { // the dm kernels need the matrix itself
+        if (!reserve(s, s->occ_dm, sizeof(double) * (size_t)nao * nao, "hipMalloc(dm)")) return false;
+        launch_dm_from_cocc(s->stream, nao, nocc, cocc, (double *)s->occ_dm.p);
+        dm = (const double *)s->occ_dm.p;
     }
     const int NP = ((nao + 15) / 16) * 16;
     const int nblk = (nao + 127) / 128;
@@ -249,12 +283,20 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
                  *gz = gga ? ao_grad + 2 * ng * nao : nullptr;
     hipStream_t st = s->stream;
 
-    if (!fast) { // the wave-specialised rho kernel symmetrises D in its prologue
+    if (use_occ) {
+        ScopedTimer t(s, "rho_occ");
+        if (!reserve(s, s->occ_cp, sizeof(double) * oplan.cp_doubles, "hipMalloc(packed cocc)")) return false;
+        const bool vec16 = (nao % 2 == 0) && ((((uintptr_t)ao | (uintptr_t)gx | (uintptr_t)gy | (uintptr_t)gz) & 15) == 0);
+        if (!hip_ok(s, launch_rho_occ(st, s->num_cu, oplan, gga, vec16, ngrid, nao, nocc, cocc, (double *)s->occ_cp.p, ao, gx, gy, gz,
+                                      rho, grad, sigma), "occupied-orbital density launch"))
+            return false;
+    }
+    if (!fast && !use_occ) { // the wave-specialised rho kernel symmetrises D in its prologue
         ScopedTimer t(s, "sym_dm");
         dim3 b(16, 16), g(NP / 16, NP / 16);
         hipLaunchKernelGGL(k_sym_dm, g, b, 0, st, nao, NP, dm, Dp);
     }
-    {
+    if (!use_occ) {
         ScopedTimer t(s, "rho");
         const int vec16 = (nao % 2 == 0) && ((((uintptr_t)ao | (uintptr_t)gx | (uintptr_t)gy | (uintptr_t)gz) & 15) == 0);
         if (fast && ws16) {
@@ -631,7 +673,7 @@ __global__ void k_accumulate_chunk(long n2, int add, const double *__restrict__ 
 
 extern "C" {
 
-int DFT_GetVersion(void) { return 2; }
+int DFT_GetVersion(void) { return 3; }
 
 XCSolver *DFT_CreateSolver(int type)
 {
@@ -671,7 +713,7 @@ void DFT_DestroySolver(XCSolver *s)
         (void)hipStreamSynchronize(s->stream);
         DevBuf *bufs[] = {&s->dsym, &s->rho, &s->sigma, &s->grad, &s->coef, &s->partial,
                           &s->slabs, &s->exc, &s->jpart, &s->kpart, &s->shells, &s->msym,
-                          &s->cdy, &s->cdc, &s->cdv, &s->ao_ws, &s->vtmp};
+                          &s->cdy, &s->cdc, &s->cdv, &s->ao_ws, &s->vtmp, &s->occ_cp, &s->occ_dm};
         for (DevBuf *b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (s->h_exc) (void)hipHostFree(s->h_exc);
@@ -683,27 +725,30 @@ void DFT_DestroySolver(XCSolver *s)
     delete s;
 }
 
-double DFT_ComputeXC64(XCSolver *s, long long ngrid, int nao, unsigned long long d_dm,
-                       unsigned long long d_ao, unsigned long long d_ao_grad,
-                       unsigned long long d_w, unsigned long long d_vxc)
+// The synchronous call: sweep + wait for Exc (shared by DFT_ComputeXC / DFT_ComputeXC64 / DFT_ComputeXCOcc)
+static double xc_call_sync(XCSolver *s, long long ngrid, int nao, unsigned long long d_dm,
+                           unsigned long long d_ao, unsigned long long d_ao_grad,
+                           unsigned long long d_w, unsigned long long d_vxc,
+                           unsigned long long d_cocc, int nocc)
 {
     if (!s) return 0.0;
     DeviceGuard dg(s);
     const double nan = std::numeric_limits<double>::quiet_NaN();
     if (s->h_exc) *s->h_exc = nan; // before anything is enqueued: the last kernel overwrites it
     if (!xc_sweep(s, (long)ngrid, nao, (const double *)d_dm, (const double *)d_ao,
-                  (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc, true))
+                  (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc, true,
+                  (const double *)d_cocc, nocc))
         return nan;
     if (s->h_exc_dev) { // Exc is written into host-mapped memory by the call's last kernel
         volatile double *hx = s->h_exc;
         if (s->spin_wait) {
-            // The word is stored by the last block of the call's last kernel, after that kernel's Vxc stores
-            // were issued: it says "Exc is final and every kernel of the call has been dispatched and all but
-            // the tail of the last one has run".  Anything the caller does with d_vxc on the SOLVER'S stream
-            // (the reference's pattern: the null stream, d_vxc.get() at dft.py:211) is ordered behind it.
-            // A consumer on ANOTHER stream, or a host read of a mapped Vxc, needs option "strict_sync" = 1,
-            // which also polls the stream until it reports complete (the reference's blocking 8-byte copy +
-            // cudaFree, dft_solver.cu:575-582; costs 8-10 us per call, measured).  Both spins are bounded by
+            // The word is stored by the call's LAST kernel.  Default: that is the one-block k_finish_exc, which stream
+            // order starts only after the Vxc reduce (and everything before it) has completed -- seeing the word means
+            // the whole call is done, for consumers on any stream and for host reads, the reference's contract
+            // (blocking 8-byte copy + cudaFree, dft_solver.cu:575-582).  With option "fuse_finish" = 1 the reduce
+            // kernel's highest-index block stores it (no finishing launch): then it only orders consumers on the
+            // SOLVER'S stream (the reference's pattern, d_vxc.get() on the null stream, dft.py:211), and
+            // "strict_sync" = 1 adds a poll of the stream to completion for the others.  Both spins are bounded by
             // the stream state: a faulted kernel or an Exc that really is NaN ends them.
             for (unsigned spins = 1; std::isnan(*hx); ++spins) {
                 if ((spins & 0xFFF) == 0 && hipStreamQuery(s->stream) != hipErrorNotReady) break;
@@ -727,6 +772,39 @@ double DFT_ComputeXC64(XCSolver *s, long long ngrid, int nao, unsigned long long
         return nan;
     if (std::isnan(out)) set_error(s, "Exc is NaN after the sweep completed (non-finite inputs)");
     return out;
+}
+
+double DFT_ComputeXC64(XCSolver *s, long long ngrid, int nao, unsigned long long d_dm,
+                       unsigned long long d_ao, unsigned long long d_ao_grad,
+                       unsigned long long d_w, unsigned long long d_vxc)
+{
+    return xc_call_sync(s, ngrid, nao, d_dm, d_ao, d_ao_grad, d_w, d_vxc, 0ULL, 0);
+}
+
+double DFT_ComputeXCOcc(XCSolver *s, long long ngrid, int nao, int nocc, unsigned long long d_cocc,
+                        unsigned long long d_dm, unsigned long long d_ao, unsigned long long d_ao_grad,
+                        unsigned long long d_w, unsigned long long d_vxc)
+{
+    if (s && !d_cocc) {
+        set_error(s, "DFT_ComputeXCOcc needs the occupied orbitals");
+        return std::numeric_limits<double>::quiet_NaN();
+    }
+    return xc_call_sync(s, ngrid, nao, d_dm, d_ao, d_ao_grad, d_w, d_vxc, d_cocc, nocc);
+}
+
+int DFT_ComputeXCOccAsync(XCSolver *s, long long ngrid, int nao, int nocc, unsigned long long d_cocc,
+                          unsigned long long d_dm, unsigned long long d_ao, unsigned long long d_ao_grad,
+                          unsigned long long d_w, unsigned long long d_vxc, unsigned long long d_exc)
+{
+    if (!s) return -1;
+    DeviceGuard dg(s);
+    if (!d_cocc) { set_error(s, "DFT_ComputeXCOccAsync needs the occupied orbitals"); return -1; }
+    if (!xc_sweep(s, (long)ngrid, nao, (const double *)d_dm, (const double *)d_ao,
+                  (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc, false, (const double *)d_cocc, nocc))
+        return -1;
+    if (d_exc && !hip_ok(s, hipMemcpyAsync((void *)d_exc, s->exc.p, sizeof(double), hipMemcpyDeviceToDevice, s->stream), "copy Exc"))
+        return -1;
+    return 0;
 }
 
 double DFT_ComputeXC(XCSolver *s, int ngrid, int nao, unsigned long long d_dm,
@@ -863,6 +941,7 @@ int DFT_SetOption(XCSolver *s, const char *key, double value)
     if (!strcmp(key, "fuse_finish")) { s->fuse_finish = value != 0.0; return 0; }
     if (!strcmp(key, "sweep_order")) { s->sweep_order = (int)value & 3; return 0; }
     if (!strcmp(key, "dbg")) { s->dbg = (int)value; return 0; }
+    if (!strcmp(key, "occ")) { s->occ = value == 1.0 ? 1 : value == 2.0 ? 2 : 0; return 0; }
     if (!strcmp(key, "ws_waves")) { s->ws_waves = value == 16.0 ? 16 : value == 8.0 ? 8 : 0; return 0; }
     if (!strcmp(key, "rho_rows")) { s->rho_rows = value == 128.0 ? 128 : 64; return 0; }
     if (!strcmp(key, "ao_pt")) { s->ao_pt = value == 16.0 ? 16 : value == 8.0 ? 8 : 0; return 0; }

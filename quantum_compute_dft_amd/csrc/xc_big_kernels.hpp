@@ -29,24 +29,6 @@ constexpr int BG_LDA = BG_BK + 2;   // 18: A-operand reads conflict-free
 constexpr int BG_LDB = BG_BN + 16;  // 272 = 16 (mod 32)
 constexpr int BG_LDQ = BG_BM + 16;  // 144
 
-__device__ __forceinline__ double2 buf_load_d2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-{
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return make_double2(__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2]));
-}
-__device__ __forceinline__ double buf_load_d1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-{
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return __hiloint2double((int)v[1], (int)v[0]);
-}
-// two consecutive doubles at byte offset voff+soff; VEC = 16-byte aligned rows (nao even)
-template <bool VEC>
-__device__ __forceinline__ double2 buf_load_pair2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-{
-    if (VEC) return buf_load_d2(r, voff, soff);
-    return make_double2(buf_load_d1(r, voff, soff), buf_load_d1(r, voff + 8, soff));
-}
-
 // ------------------------------------------------------------------ rho ----
 // Workgroup tile 128 rows x 128 columns of X (wave tile 64 x 32 = 4x2 MFMA tiles): the row-dot
 // epilogue needs ~100 VGPRs of its own, which a 4x4 wave tile (128 accumulator VGPRs) spills.

@@ -21,16 +21,11 @@
 // D[row = (l>>4) + 4r][col = l&15].
 #pragma once
 #include <hip/hip_runtime.h>
+#include "device_util.hpp"
 #include "xc_functionals.hpp"
 
 namespace qcdft {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
-{
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
 
 // Ds = (D + D^T)/2, zero-padded to NP x NP (NP = 16*ceil(nao/16)).
 __global__ void k_sym_dm(int nao, int NP, const double *__restrict__ D, double *__restrict__ Dp)
