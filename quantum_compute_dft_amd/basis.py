@@ -204,7 +204,11 @@ def load_basis_file(path, name=None):
     if not table:
         raise ValueError(f"{path}: no basis functions found")
     name = (name or os.path.splitext(os.path.basename(path))[0]).lower().replace("_", "-")
-    register_basis(name, table)
+    # merged element by element into a basis of that name if there is one (the file's elements win): a file with only
+    # the P and S tables on top of the shipped def2-svp keeps H, C, N, O (dft.py --basis def2-svp --basis-file P_S.nw)
+    merged = dict(_BASIS_SETS.get(name, {}))
+    merged.update(table)
+    register_basis(name, merged)
     return name
 
 

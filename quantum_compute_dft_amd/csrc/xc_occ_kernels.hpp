@@ -18,8 +18,8 @@
 // registers against those loads and X never touches LDS either.  LDS holds only
 //   * C, zero-padded, as [nu][orbital] with an ODD leading dimension: both fragment reads (phase 1: 2 k-rows x 16
 //     orbitals per 32 lanes, k-rows 16 apart; phase 2: 16 even rows x 2 orbitals) hit 32 distinct 8-byte banks;
-//   * per wave one 16 x 32 chunk of AO (ld 33) that turns the quad-coalesced global loads (4 lanes = 64
-//     contiguous bytes of a row) into B-operand fragments; wave-private, so no barrier guards it.
+//   * per wave one 16 x 32 chunk of AO (ld 33) that turns the coalesced global loads (the same (row, seg)
+//     pattern) into B-operand fragments; wave-private, so no barrier guards it.
 // RESIDENT: all of C stays in LDS (nao <= 128 and the like), the workgroups are persistent and their waves never
 // meet at a barrier after the prologue.  Otherwise C streams through a double-buffered 32-row chunk per step
 // (phase 1: k-chunk c, phase 2: column block J -- the same rows of C), one barrier per step.
@@ -27,6 +27,7 @@
 // linear in the orbital sum).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <type_traits>
 #include "device_util.hpp"
 
@@ -128,10 +129,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_rho_occ(long ngrid, int nao, int
 
     const long plane = ngrid * (long)nao;
     const long nrb = (ngrid + 16 * NW - 1) / (16 * NW);
-    // AO chunk loads: lane (row = lane>>2, p = lane&3), four loads m: columns 32c + 8m + 2p, +1
-    const int a_row = lane >> 2, a_p = lane & 3;
-    const unsigned a_voff = (unsigned)(a_row * nao + 2 * a_p) * 8u;
-    // gradient block loads: lane (q, seg = li), rows 4r + q, columns 32J + 2 li, +1
+    // plane loads, AO chunks and gradient blocks alike: lane (q, seg = li), rows 4r + q, columns 32c + 2 li, +1 --
+    // 16 lanes = 256 contiguous bytes of one grid row, four rows per instruction
     unsigned g_voff[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) g_voff[r] = (unsigned)((4 * r + q) * nao + 2 * li) * 8u;
@@ -164,7 +163,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_rho_occ(long ngrid, int nao, int
                 const __amdgpu_buffer_rsrc_t rr = c < nch ? r0 : r0dead; // past the last chunk: no traffic, same count
                 const unsigned soff = (unsigned)(c * OC_KC) * 8u;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) av[m] = buf_load_pair2<VEC>(rr, a_voff + 64 * m, soff);
+                for (int r = 0; r < 4; ++r) av[r] = buf_load_pair2<VEC>(rr, g_voff[r], soff);
+                __builtin_amdgcn_sched_barrier(0); // all loads of a group leave together (see issue_g)
             };
             issue_ao(0);
             for (int c = 0; c < nch; ++c) {
@@ -177,9 +177,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_rho_occ(long ngrid, int nao, int
                     cp_fetch(nx);
                 }
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    As[a_row * OC_LDA + 8 * m + 2 * a_p] = av[m].x;
-                    As[a_row * OC_LDA + 8 * m + 2 * a_p + 1] = av[m].y;
+                for (int r = 0; r < 4; ++r) {
+                    As[(4 * r + q) * OC_LDA + 2 * li] = av[r].x;
+                    As[(4 * r + q) * OC_LDA + 2 * li + 1] = av[r].y;
                 }
                 __builtin_amdgcn_wave_barrier();
                 issue_ao(c + 1);
@@ -216,6 +216,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_rho_occ(long ngrid, int nao, int
                 double2 gv[GSETS][3][4];
                 auto issue_g = [&](auto S, int J) {
                     constexpr int st = decltype(S)::value;
+                    __builtin_amdgcn_sched_barrier(0);
                     const bool in = J < nch;
                     const __amdgpu_buffer_rsrc_t a = in ? r1 : r1d, b = in ? r2 : r2d, c = in ? r3 : r3d;
                     const unsigned soff = (unsigned)(J * OC_KC) * 8u;
@@ -225,6 +226,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_rho_occ(long ngrid, int nao, int
                         gv[st][1][r] = buf_load_pair2<VEC>(b, g_voff[r], soff);
                         gv[st][2][r] = buf_load_pair2<VEC>(c, g_voff[r], soff);
                     }
+                    // Pinned: left to itself the scheduler trades these twelve loads in flight for registers (it
+                    // interleaved them one by one with their waits to reach four waves per SIMD: 106 -> 126 us)
+                    __builtin_amdgcn_sched_barrier(0);
                 };
                 auto block = [&](auto S, int J, int Jnext) { // MFMAs of block J, then its row dots against set S
                     constexpr int st = decltype(S)::value;
@@ -246,6 +250,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_rho_occ(long ngrid, int nao, int
                             xe = mfma_f64(y[t][r], Ce[16 * t + 4 * r], xe);
                             xo = mfma_f64(y[t][r], Co[16 * t + 4 * r], xo);
                         }
+                    __builtin_amdgcn_sched_barrier(0); // both tiles' MFMAs run under the loads' latency, the waits come after
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         s1[r] += xe[r] * gv[st][0][r].x + xo[r] * gv[st][0][r].y;
@@ -295,6 +300,253 @@ __global__ __launch_bounds__(64 * NW, 2) void k_rho_occ(long ngrid, int nao, int
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Row-shared form for a resident C (nao <= ~250 with nocc <= 64): the FOUR WAVES OF A WORKGROUP SHARE 16 GRID ROWS and
+// split their columns -- wave w takes k-chunk w of phase 1 and column block w of phase 2 (the same 32 rows of C) --
+// so that at any moment a workgroup reads whole, consecutive grid rows.  That is what HBM rewards
+// (tools/stream_pattern_probe3.hip, profiles/r03_stream_pattern_probe3.txt: the four planes of Benzene/def2-SVP in
+// 85 us = 6.2 TB/s this way against 96-107 us when every wave walks the 32-column blocks of its own 16 rows, and the
+// more workgroups per CU the slower the latter).  Price: the partial Y^T of the four k-chunks meet in LDS (each wave
+// stores its result registers as they are, every wave reads the four copies of its own lane's slots back and adds:
+// the lane <-> element map of the MFMA result IS the A-operand map of phase 2), two barriers per 16 rows, and the
+// per-row gradient sums of the four column blocks are added by wave 0 one tile later.
+// Results leave in BURSTS: the per-row outputs (rho, grad rho, sigma: 40 bytes per grid row, 1 % of the traffic) are
+// collected in LDS and written every OC_OT tiles by the whole workgroup.  Stored tile by tile they cost 10 us of 85
+// (tools/stream_pattern_probe4.hip, profiles/r03_stream_pattern_probe4.txt: "D + stores") -- a trickle of writes keeps
+// turning the HBM channels around under the read stream.
+constexpr int OC_OT = 16, OC_OR = OC_OT + 1; // tiles per burst, ring slots
+
+template <int NTO, bool GRAD, bool VEC, bool MULTI>
+__global__ __launch_bounds__(256, 2) void k_rho_occ_rs(long ngrid, int nao, int nch,
+                                                       const double *__restrict__ ao,
+                                                       const double *__restrict__ gx,
+                                                       const double *__restrict__ gy,
+                                                       const double *__restrict__ gz,
+                                                       const double *__restrict__ cocc, int nocc,
+                                                       double *__restrict__ rho,
+                                                       double *__restrict__ grad,
+                                                       double *__restrict__ sigma)
+{
+    using C = OccCfg<NTO>;
+    constexpr int YW = NTO * 256 > 16 * OC_LDA ? NTO * 256 : 16 * OC_LDA; // doubles per wave: AO chunk, then Y partial
+    extern __shared__ __attribute__((aligned(32))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+    double *const Cs = lds;
+    double *const region = lds + (size_t)nch * C::CHUNK;
+    double *const As = region + wave * YW;
+    double *const Gs = region + 4 * YW; // [2][4 waves][16 rows][3]
+    double *const Ob = Gs + 2 * 4 * 16 * 3; // [OC_OR slots][16 rows][4]: rho, 2 sum_x, 2 sum_y, 2 sum_z
+
+    const long plane = ngrid * (long)nao;
+    const long ntile = (ngrid + 15) / 16;
+    unsigned g_voff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g_voff[r] = (unsigned)((4 * r + q) * nao + 2 * li) * 8u;
+    const int kq = 16 * (q & 1) + 8 * (q >> 1);
+    const bool mine = wave < nch; // this wave owns chunk / block `wave` (nao <= 96 leaves waves without one)
+
+    // One group of each kind is ALWAYS in flight per wave: the AO chunk of the next tile is issued as soon as this
+    // tile's has been staged, the gradient block of the next tile as soon as this tile's has been consumed -- the
+    // registers are free at those points, so the prefetch costs none, and every wait is a counted one (AO groups
+    // and gradient groups alternate in issue order).  Dead groups (past the grid, or a wave without a block) go
+    // through a zero-record descriptor: no traffic, same count.
+    double2 av[4], gv[3][4];
+    auto issue_ao = [&](double2 (&dst)[4], long tile, int c) {
+        const bool in = tile < ntile && c < nch;
+        const __amdgpu_buffer_rsrc_t rr = plane_tile_rsrc(ao, plane, (in ? tile : 0) * 16 * (long)nao, in);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[r] = buf_load_pair2<VEC>(rr, g_voff[r], (unsigned)(c * OC_KC) * 8u);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto issue_g = [&](double2 (&dst)[3][4], long tile, int J) {
+        const bool in = tile < ntile && J < nch;
+        const long e0 = (in ? tile : 0) * 16 * (long)nao;
+        const __amdgpu_buffer_rsrc_t a = plane_tile_rsrc(gx, plane, e0, in), b = plane_tile_rsrc(gy, plane, e0, in),
+                                     c = plane_tile_rsrc(gz, plane, e0, in);
+        const unsigned soff = (unsigned)(J * OC_KC) * 8u;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dst[0][r] = buf_load_pair2<VEC>(a, g_voff[r], soff);
+            dst[1][r] = buf_load_pair2<VEC>(b, g_voff[r], soff);
+            dst[2][r] = buf_load_pair2<VEC>(c, g_voff[r], soff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto finish_rows = [&](int jt, int pb) { // wave 0, lanes 0..15: gradient of the rows of local tile `jt` from the four partials
+        if (lane < 16) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double *p = Gs + ((pb * 4) * 16 + lane) * 3 + k;
+                Ob[((jt % OC_OR) * 16 + lane) * 4 + 1 + k] = 2.0 * ((p[0] + p[48]) + (p[96] + p[144]));
+            }
+        }
+    };
+    auto flush = [&](int j0, int j1) { // local tiles [j0, j1) (at most OC_OT): thread = (tile, row)
+        const int j = j0 + (tid >> 4), row = tid & 15;
+        const long g = ((long)blockIdx.x + (long)j * gridDim.x) * 16 + row;
+#ifdef QCDFT_OCC_NO_STORE // ablation build only (tools/occ_ablate.hip)
+        if (j < j1 && g < 0) {
+#else
+        if (j < j1 && g < ngrid) {
+#endif
+            const double *o = Ob + ((j % OC_OR) * 16 + row) * 4;
+            rho[g] = o[0];
+            if (GRAD) {
+                const double ax = o[1], ay = o[2], az = o[3];
+                grad[3 * g + 0] = ax;
+                grad[3 * g + 1] = ay;
+                grad[3 * g + 2] = az;
+                sigma[g] = ax * ax + ay * ay + az * az;
+            }
+        }
+    };
+    auto stage_and_multiply = [&](const double2 (&src)[4], int c, d4 (&y)[NTO]) { // chunk c of phase 1
+#ifdef QCDFT_OCC_ABL_NOCOMPUTE // ablation builds only (tools/occ_ablate.hip)
+        for (int r = 0; r < 4; ++r) y[0][r] += src[r].x + src[r].y;
+        return;
+#endif
+        const double *Cc = Cs + (size_t)c * C::CHUNK;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            As[(4 * r + q) * OC_LDA + 2 * li] = src[r].x;
+            As[(4 * r + q) * OC_LDA + 2 * li + 1] = src[r].y;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const double b = As[li * OC_LDA + kq + s];
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) y[t] = mfma_f64(Cc[(kq + s) * C::LDC + 16 * t + li], b, y[t]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto block_dots = [&](const double2 (&g)[3][4], int J, const d4 (&y)[NTO], double (&s1)[4], double (&s2)[4], double (&s3)[4]) {
+#ifdef QCDFT_OCC_ABL_NOCOMPUTE
+        for (int r = 0; r < 4; ++r) { s1[r] += g[0][r].x + g[0][r].y + y[0][r]; s2[r] += g[1][r].x + g[1][r].y; s3[r] += g[2][r].x + g[2][r].y; }
+        return;
+#endif
+        const double *Ce = Cs + (size_t)J * C::CHUNK + (2 * li) * C::LDC + q, *Co = Ce + C::LDC;
+        d4 xe = (d4){0.0, 0.0, 0.0, 0.0}, xo = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < NTO; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xe = mfma_f64(y[t][r], Ce[16 * t + 4 * r], xe);
+                xo = mfma_f64(y[t][r], Co[16 * t + 4 * r], xo);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s1[r] += xe[r] * g[0][r].x + xo[r] * g[0][r].y;
+            s2[r] += xe[r] * g[1][r].x + xo[r] * g[1][r].y;
+            s3[r] += xe[r] * g[2][r].x + xo[r] * g[2][r].y;
+        }
+    };
+
+    int it = 0, flushed = 0;
+    issue_ao(av, blockIdx.x, wave);
+    if (GRAD) issue_g(gv, blockIdx.x, wave);
+    // all of C, zero-padded to [32 nch][NOP], once per (persistent) workgroup, straight from the caller's (nao, nocc)
+    // array -- under the first tile's loads
+    for (int e = tid; e < OC_KC * nch * C::NOP; e += 256) {
+        const int nu = e / C::NOP, o = e % C::NOP;
+        Cs[nu * C::LDC + o] = (nu < nao && o < nocc) ? cocc[(size_t)nu * nocc + o] : 0.0;
+    }
+    __syncthreads();
+    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x, ++it) {
+        const long next = tile + gridDim.x;
+        d4 y[NTO];
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) y[t] = (d4){0.0, 0.0, 0.0, 0.0};
+        // ------------------------------------------------ phase 1: this wave's k-chunks of Y^T = C^T . AO^T
+        if (mine) stage_and_multiply(av, wave, y);
+        else __builtin_amdgcn_s_waitcnt(0); // keeps the issue order of a wave without a chunk like the others'
+        issue_ao(av, next, wave);
+        if (MULTI) {
+            for (int c = wave + 4; c < nch; c += 4) { // nao > 128: further chunks, loaded in place
+                double2 ax[4];
+                issue_ao(ax, tile, c);
+                stage_and_multiply(ax, c, y);
+            }
+        }
+        // partial Y^T of this wave, registers as they are: slot (t, lane) holds the d4
+#ifndef QCDFT_OCC_ABL_NOEXCHANGE
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) *reinterpret_cast<d4 *>(As + (t * 64 + lane) * 4) = y[t];
+#endif
+        lds_barrier(); // B1: partials (and the previous tile's gradient partials) are in LDS
+        if (GRAD && wave == 0 && it > 0) finish_rows(it - 1, (it - 1) & 1);
+#ifndef QCDFT_OCC_ABL_NOEXCHANGE
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) {
+            const d4 a = *reinterpret_cast<const d4 *>(region + 0 * YW + (t * 64 + lane) * 4);
+            const d4 b = *reinterpret_cast<const d4 *>(region + 1 * YW + (t * 64 + lane) * 4);
+            const d4 c = *reinterpret_cast<const d4 *>(region + 2 * YW + (t * 64 + lane) * 4);
+            const d4 d = *reinterpret_cast<const d4 *>(region + 3 * YW + (t * 64 + lane) * 4);
+            y[t] = (a + b) + (c + d); // the same order in every wave: all four hold bitwise the same Y
+        }
+#endif
+        lds_barrier(); // B2: everyone has read; the regions may take the next AO chunks
+        if (it - flushed == OC_OT) { // tiles [flushed, it) are complete in the ring (their gradients since B1 .. B2)
+            flush(flushed, it);
+            flushed = it;
+        }
+        if (wave == 1) { // rho of the 16 rows
+            double loc = 0.0;
+#pragma unroll
+            for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) loc += y[t][r] * y[t][r];
+            loc += __shfl_xor(loc, 16, 64);
+            loc += __shfl_xor(loc, 32, 64);
+            if (lane < 16) Ob[((it % OC_OR) * 16 + lane) * 4] = loc;
+        }
+        // ------------------------------------------------ phase 2: this wave's column blocks of X = Y . C^T, row dots
+        if (GRAD) {
+            double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, s3[4] = {0, 0, 0, 0};
+            if (mine) block_dots(gv, wave, y, s1, s2, s3);
+            else __builtin_amdgcn_s_waitcnt(0);
+            issue_g(gv, next, wave);
+            if (MULTI) {
+                for (int J = wave + 4; J < nch; J += 4) {
+                    double2 ge[3][4];
+                    issue_g(ge, tile, J);
+                    block_dots(ge, J, y, s1, s2, s3);
+                }
+            }
+            double *gp = Gs + (((it & 1) * 4 + wave) * 16) * 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#ifdef QCDFT_OCC_ABL_NOREDUCE
+                const double a = s1[r], b = s2[r], c = s3[r];
+#else
+                const double a = row16_sum(s1[r]), b = row16_sum(s2[r]), c = row16_sum(s3[r]);
+#endif
+                if (li == 0) {
+                    gp[(q + 4 * r) * 3 + 0] = a;
+                    gp[(q + 4 * r) * 3 + 1] = b;
+                    gp[(q + 4 * r) * 3 + 2] = c;
+                }
+            }
+        }
+    }
+    lds_barrier();
+    if (GRAD && wave == 0 && it > 0) finish_rows(it - 1, (it - 1) & 1);
+    lds_barrier();
+    flush(flushed, it);
+}
+
+// bytes of dynamic LDS of k_rho_occ_rs
+inline size_t occ_rs_lds_bytes(int nto, int nch)
+{
+    const size_t yw = (size_t)std::max(nto * 256, 16 * OC_LDA);
+    return sizeof(double) * ((size_t)nch * OC_KC * (16 * nto + 1) + 4 * yw + 2 * 4 * 16 * 3 + (size_t)OC_OR * 16 * 4);
 }
 
 } // namespace qcdft

@@ -32,6 +32,9 @@ def main(argv=None):
     p.add_argument("--ao", default="resident", choices=["resident", "direct"],
                    help="resident: AO values and gradients of the whole grid stay in HBM (the reference's layout, dft.py:155,172); "
                         "direct: they are re-evaluated chunk by chunk inside every XC call (DFT_ComputeXCDirect), memory ~100 MB")
+    p.add_argument("--xc-occ", type=int, default=1, choices=[0, 1],
+                   help="1 (default): the XC sweep's density step through the occupied orbitals (DFT_ComputeXCOcc, 4 nao nocc flops "
+                        "per grid point); 0: the reference's call with the full density matrix (DFT_ComputeXC, dft.py:206)")
     p.add_argument("--both-quirks", action="store_true",
                    help="LDA/GGA: run the SCF twice, with the reference's formulas as shipped (its CUDA path) and with the "
                         "corrected VWN5 / PBE-c derivatives (what PySCF's slater,vwn5 / PBE,PBE compute), and report both energies")
@@ -79,15 +82,18 @@ def main(argv=None):
     try:
         backend = scf.HipBackend(inp, args.functional, args.lib, quirks=bool(args.quirks), rank=rank, world=world, device=device,
                                  device_resident=None if args.device_resident < 0 else bool(args.device_resident),
-                                 eigensolver=args.eigensolver, ao_mode=args.ao)
+                                 eigensolver=args.eigensolver, ao_mode=args.ao, xc_occ=bool(args.xc_occ))
     except Exception as e:  # dft.py:149-153
         print(e)
         sys.exit(1)
     print(f"GPU Init Time: {backend.init_time:.4f}s" + (f"  ({world} ranks: grid block + Cholesky-vector slice per GPU)" if world > 1 else ""))
     res = scf.run_scf(inp, backend, args.functional)
+    eig_stats = dict(backend.occ_solver.stats) if backend.occ_solver is not None else None   # of THIS run (the second one below adds to the counters)
     other = None
     if args.both_quirks and args.functional != "B3LYP":   # B3LYP's four components are derivative-correct: one answer
         backend.solver.set_option("quirks", 0 if args.quirks else 1)
+        if backend.occ_solver is not None:
+            backend.occ_solver.reset()            # fresh full solve: the second SCF does not start from the first one's rotation
         other = scf.run_scf(inp, backend, args.functional, log=None)
         backend.solver.set_option("quirks", 1 if args.quirks else 0)
     if res["converged"]:
@@ -102,7 +108,7 @@ def main(argv=None):
         print(f"Median per cycle after the first: XC {res['xc_ms']:.4f} ms, J/K {res['jk_ms']:.4f} ms ({args.eri} ERI), "
               f"whole SCF iteration {res['iter_ms']:.4f} ms ({res['cycles']} cycles)")
         if backend.occ_solver is not None:
-            st = backend.occ_solver.stats
+            st = eig_stats
             print(f"Eigensolver: {st['rotated']} cycles by occupied-subspace rotation ({st['inner_steps']} fixed-point steps), {st['exact']} by full diagonalisation")
         eig_dev = "occupied-subspace rotation, hipSOLVER eigh as fallback," if backend.occ_solver is not None else "hipSOLVER eigh"
         print("Host part of the cycle: " + (f"device-resident (Fock build, DIIS, {eig_dev} in HBM)" if backend.device_resident
@@ -122,7 +128,7 @@ def main(argv=None):
               "E_ex_hf": res.get("E_ex_hf"), "E_nuc": float(inp.E_nuc), "total_time_s": res.get("total_time"),
               "xc_ms_avg": res.get("xc_ms_avg"), "xc_ms": res.get("xc_ms"), "jk_ms": res.get("jk_ms"), "iter_ms": res.get("iter_ms"),
               "cycle_ms": res.get("cycle_ms"), "gpu_init_s": backend.init_time, "device_resident": bool(backend.device_resident), "ao": args.ao, "eigensolver": args.eigensolver,
-              "eigensolver_stats": dict(backend.occ_solver.stats) if backend.occ_solver is not None else None}
+              "eigensolver_stats": eig_stats, "xc_occ": int(backend.xc_occ)}
     if other is not None:
         record["E_tot_other_quirks"] = other.get("E_tot"); record["other_quirks"] = 0 if args.quirks else 1
     line = json.dumps(record)

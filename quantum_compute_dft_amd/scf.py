@@ -166,6 +166,11 @@ class OccupiedRotation:
         self.U = None
         self.stats = {"exact": 0, "rotated": 0, "inner_steps": 0}
 
+    def reset(self):
+        """Forget the followed subspace and the counters: the next call is a full solve (a second SCF on the same backend)."""
+        self.U = None
+        self.stats = {"exact": 0, "rotated": 0, "inner_steps": 0}
+
     def _exact(self, F):
         t = self.t
         Fp = self.X.T @ F @ self.X
@@ -311,7 +316,7 @@ class HipBackend:
     rows of J (and, through the (i,k) view, its partial K); the all-reduce assembles them."""
 
     def __init__(self, inp, functional, lib_path=None, quirks=True, rank=0, world=1, device=None, group=None,
-                 device_resident=None, device_from=200, eigensolver="auto", ao_mode="resident", ao_chunk=0):
+                 device_resident=None, device_from=200, eigensolver="auto", ao_mode="resident", ao_chunk=0, xc_occ=True):
         import torch
         from .build import library_path
         from .grid_shard import ReplicaSync, ShardedFock, eri_row_bounds, shard_bounds, vector_bounds
@@ -341,6 +346,9 @@ class HipBackend:
         if ao_mode not in ("resident", "direct"):
             raise ValueError(f"ao_mode {ao_mode!r}: expected 'resident' or 'direct'")
         self.ao_mode, self.ao_chunk, self.shells, self.d_coords = ao_mode, int(ao_chunk), inp.shells, d_coords
+        # the sweep's density step through the occupied orbitals (DFT_ComputeXCOcc: the loop holds cocc with
+        # dm = cocc cocc^T in every cycle, dft.py:181-182); False = the reference's call with the full matrix
+        self.xc_occ = bool(xc_occ)
         self.d_ao = self.d_gr = None
         if ao_mode == "resident":
             self.d_ao = torch.zeros((n1, nao), dtype=f64, device=self.dev)
@@ -464,7 +472,10 @@ class HipBackend:
         if self.ao_mode == "direct":
             self.solver.compute_xc_direct(self.shells, self.ngrid, self.d_coords, self.d_w, self.d_dm, self.d_v, self._d_exc, self.ao_chunk)
             return float(self._d_exc.item())                                             # device sync, like the ABI call
-        exc = self.solver.compute_xc(self.ngrid, self.nao, self.d_dm, self.d_ao, self.d_w, self.d_v, self.d_gr)
+        if self.xc_occ:
+            exc = self.solver.compute_xc_occ(self.ngrid, self.nao, self.nocc, self.d_cocc, self.d_ao, self.d_w, self.d_v, self.d_gr, self.d_dm)
+        else:
+            exc = self.solver.compute_xc(self.ngrid, self.nao, self.d_dm, self.d_ao, self.d_w, self.d_v, self.d_gr)
         self.torch.cuda.synchronize()                                                # dft.py:205-208
         return exc
 

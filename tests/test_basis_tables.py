@@ -89,3 +89,26 @@ def test_missing_element_names_the_loader():
     syms, xyz = basis.parse_xyz("S 0 0 0; H 1.3 0 0; H -0.2 1.3 0")
     with pytest.raises(KeyError, match="load_basis_file"):
         basis.build_shells(syms, xyz, "def2-svp")
+
+
+def test_a_file_with_some_elements_is_merged_into_the_named_basis(tmp_path):
+    """`dft.py --basis def2-svp --basis-file P_S.nw`: a file that only holds tables for P and S must ADD them to the
+    shipped def2-svp (H, C, N, O stay), the file's elements winning over shipped ones of the same symbol."""
+    keep = dict(basis._BASIS_SETS["def2-svp"])
+    try:
+        path = tmp_path / "P_S.nw"
+        fake = {"P": basis._BASIS_SETS["sto-3g"]["P"], "S": basis._BASIS_SETS["sto-3g"]["S"]}   # stand-in numbers: only the merge is tested
+        _write_nwchem(path, fake)
+        assert basis.load_basis_file(str(path), "def2-svp") == "def2-svp"
+        assert set(basis._BASIS_SETS["def2-svp"]) >= {"H", "C", "N", "O", "P", "S"}
+        assert basis._BASIS_SETS["def2-svp"]["C"] == keep["C"]
+        syms, xyz = basis.parse_xyz("S 0 0 0; H 1.3 0 0; H -0.2 1.3 0; C 3 0 0")
+        assert basis.build_shells(syms, xyz, "def2-svp").nao > 0
+        # an element that IS shipped is replaced by the file's table
+        path2 = tmp_path / "H_only.nw"
+        _write_nwchem(path2, {"H": basis._BASIS_SETS["sto-3g"]["H"]})
+        basis.load_basis_file(str(path2), "def2-svp")
+        assert basis._BASIS_SETS["def2-svp"]["H"] == [(l, [(float(e), float(c)) for e, c in p]) for l, p in basis._BASIS_SETS["sto-3g"]["H"]]
+        assert basis._BASIS_SETS["def2-svp"]["C"] == keep["C"]
+    finally:
+        basis._BASIS_SETS["def2-svp"] = keep
