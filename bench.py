@@ -57,6 +57,7 @@ F64_MFMA_PEAK_TF = 78.6      # AMD datasheet fp64 matrix peak (the local guide l
                              # 77.9 TF on constant operands at 2.39 GHz, ~59 TF on real data (clock drops to ~1.8 GHz),
                              # profiles/r01_mfma_f64_probe2.txt and DESIGN.md
 SEED = 20260128
+NOCC = {114: 21, 24: 5, 494: 47, 80: 47, 246: 47, 1150: 250}   # closed-shell occupied orbitals: Benzene 21, H2O 5, Anthracene 47, C33H56N7O17P3S 250
 
 
 def synth(ngrid, nao, need_grad, dev, seed):
@@ -65,10 +66,10 @@ def synth(ngrid, nao, need_grad, dev, seed):
     ao = 0.4 * torch.randn((ngrid, nao), dtype=torch.float64, device=dev, generator=g)
     gr = 0.3 * torch.randn((3, ngrid, nao), dtype=torch.float64, device=dev, generator=g) if need_grad else None
     w = 0.05 * torch.rand((ngrid,), dtype=torch.float64, device=dev, generator=g)
-    nocc = -(-nao // 5)
+    nocc = NOCC.get(nao, -(-nao // 5))     # occupied orbitals of the named molecules; SURVEY's ceil(nao/5) elsewhere
     C = 0.7 * torch.randn((nao, nocc), dtype=torch.float64, device=dev, generator=g)
     dm = 2.0 * C @ C.T
-    return dm.contiguous(), ao, gr, w
+    return dm.contiguous(), ao, gr, w, (float(np.sqrt(2.0)) * C).contiguous()      # dm = cocc cocc^T
 
 
 def kernel_model(name, xc, ngrid, nao):
@@ -245,7 +246,9 @@ def k_build_mfma(lib_path, dev, nao=494, nocc=47, naux=3000, reps=5):
             "achieved": (fl_half + fl_syrk) / t_k / 1e9, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
             "frac": (fl_half + fl_syrk) / t_k / 1e9 / F64_MFMA_PEAK_TF,
             "full_square_equivalent_tflops": 2 * fl_half / t_k / 1e9,
-            "j_pass_gbs": 8.0 * naux * nao * nao / acc["cd_j"] / 1e6}
+            # the J pass (k_cd_axpy) reads the upper triangle of every symmetric vector only: 4 naux nao (nao + 1) bytes
+            "j_pass_gbs": 4.0 * naux * nao * (nao + 1) / acc["cd_j"] / 1e6,
+            "j_pass_note": "bytes the kernel reads (upper triangles), not the full-square 8 naux nao^2"}
 
 
 def pmc_traffic(workload, kernels):
@@ -342,11 +345,14 @@ def scf_real_leg(lib_path, dev, molecule="Benzene", functional="GGA", basis_name
                        f"integrals and level-3 grid (host build {t_build:.1f} s, not timed)",
            "statistic": "median per cycle after the first; thresholds of dft.py:243"}
     for name, ii in (("dense_eri", inp), ("factorised_j", inp_cd)):
-        for eig in ("auto", "exact"):
-            be = scf.HipBackend(ii, functional, lib_path, device=dev, eigensolver=eig)
+        # auto / exact: the XC sweep through DFT_ComputeXCOcc (the loop holds cocc); abi_xc: eigensolver auto with the
+        # reference ABI's DFT_ComputeXC (full density matrix) beside it
+        for eig, occ in (("auto", True), ("exact", True), ("abi_xc", False)):
+            be = scf.HipBackend(ii, functional, lib_path, device=dev, eigensolver="auto" if eig == "abi_xc" else eig, xc_occ=occ)
             r = scf.run_scf(ii, be, functional, log=None)
             out[f"{name}_{eig}"] = {"ms_per_cycle": r["iter_ms"], "xc_ms": r["xc_ms"], "jk_ms": r["jk_ms"], "cycles": r["cycles"],
                                     "converged": bool(r["converged"]), "E_tot": r["E_tot"], "total_ms": 1e3 * r["total_time"],
+                                    "xc_entry_point": "DFT_ComputeXCOcc" if occ else "DFT_ComputeXC",
                                     "eigensolver": dict(be.occ_solver.stats) if be.occ_solver is not None else "eigh(F, S) every cycle"}
             del be
     del inp, inp_cd
@@ -365,9 +371,16 @@ def scf_real_sharded_leg(lib_path, dev, world, rank, molecule="Anthracene", func
     t0 = time.perf_counter()
     inp = inputs.build(molecule, basis_name, 3, device=dev, verbose=False, eri_mode="cholesky", chol_tol=tol)
     t_build = time.perf_counter() - t0
+    abi = None
+    if world == 1:   # the same SCF with the reference ABI's DFT_ComputeXC (full density matrix) in the sweep, beside the default
+        be = scf.HipBackend(inp, functional, lib_path, device=dev, xc_occ=False)
+        ra = scf.run_scf(inp, be, functional, log=None)
+        abi = {"xc_entry_point": "DFT_ComputeXC", "ms_per_cycle": ra["iter_ms"], "xc_ms": ra["xc_ms"], "jk_ms": ra["jk_ms"], "cycles": ra["cycles"], "E_tot": ra["E_tot"]}
+        del be
     be = scf.HipBackend(inp, functional, lib_path, rank=rank, world=world, device=dev)
     r = scf.run_scf(inp, be, functional, log=None)
-    out = {"workload": f"{molecule} {functional}/{basis_name}: nao {inp.shells.nao}, {inp.grids.size} grid points, {inp.chol.shape[0]} Cholesky vectors "
+    out = {"xc_entry_point": "DFT_ComputeXCOcc (occupied orbitals; scf.HipBackend default)", "abi_xc_entry": abi,
+           "workload": f"{molecule} {functional}/{basis_name}: nao {inp.shells.nao}, {inp.grids.size} grid points, {inp.chol.shape[0]} Cholesky vectors "
                        f"({tol:g}), sharded over {world} GPU(s); inputs built on every rank in {t_build:.1f} s (not timed)",
            "scaling": "strong", "ms_per_cycle": r["iter_ms"], "xc_ms": r["xc_ms"], "jk_ms": r["jk_ms"], "cycles": r["cycles"],
            "converged": bool(r["converged"]), "E_tot": r["E_tot"], "total_ms": 1e3 * r["total_time"],
@@ -388,45 +401,58 @@ def strong_leg(lib_path, dev, dist, backend, world, rank, workload, steps=6, war
     xc, nao, ngrid = WORKLOADS[workload]
     lo, hi = shard_bounds(ngrid, world, rank)
     n_loc = hi - lo
-    dm, ao, gr, w = synth(max(n_loc, 16), nao, xc != "LDA", dev, SEED + 7919 * (rank + 1))
+    dm, ao, gr, w, cocc = synth(max(n_loc, 16), nao, xc != "LDA", dev, SEED + 7919 * (rank + 1))
     if world > 1:
-        if backend == "nccl":
-            dist.broadcast(dm, 0)
-        else:
-            h = dm.cpu(); dist.broadcast(h, 0); dm.copy_(h)
+        for t_ in (dm, cocc):
+            if backend == "nccl":
+                dist.broadcast(t_, 0)
+            else:
+                h = t_.cpu(); dist.broadcast(h, 0); t_.copy_(h)
     solver = q.DFTSolverWrapper(lib_path, xc)
+    nocc = cocc.shape[1]
     out = torch.zeros(nao * nao + 1, dtype=torch.float64, device=dev)
     d_v, d_e = out[: nao * nao], out[nao * nao:]
-    rows = []
-    for it in range(warmup + steps):
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        if n_loc:
-            solver.compute_xc_async(n_loc, nao, dm, ao, w, d_v, d_e, gr)
-        else:
-            out.zero_()
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        if world > 1:
-            if backend == "nccl":
-                dist.all_reduce(out)
+    def measure(entry):
+        rows = []
+        for it in range(warmup + steps):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            if not n_loc:
+                out.zero_()
+            elif entry == "occ":
+                solver.compute_xc_occ_async(n_loc, nao, nocc, cocc, ao, w, d_v, d_e, gr, dm)
             else:
-                h = out.cpu(); dist.all_reduce(h); out.copy_(h)
-        exc = float(d_e.item()); t2 = time.perf_counter()
-        if it >= warmup:
-            rows.append((t1 - t0, t2 - t1, t2 - t0))
-    t = torch.tensor(rows, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # slowest rank per step
-    med = t.median(dim=0).values.tolist()
+                solver.compute_xc_async(n_loc, nao, dm, ao, w, d_v, d_e, gr)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            if world > 1:
+                if backend == "nccl":
+                    dist.all_reduce(out)
+                else:
+                    h = out.cpu(); dist.all_reduce(h); out.copy_(h)
+            exc = float(d_e.item()); t2 = time.perf_counter()
+            if it >= warmup:
+                rows.append((t1 - t0, t2 - t1, t2 - t0))
+        t = torch.tensor(rows, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)          # slowest rank per step
+        med = t.median(dim=0).values.tolist()
+        return {"ms_per_step": 1e3 * med[2], "sweep_ms": 1e3 * med[0], "allreduce_ms": 1e3 * med[1], "grid_points_per_sec": ngrid / med[2],
+                "exc": exc, "hbm_frac": b_alg / med[2] / 1e9 / HBM_PEAK_GBS, "mfma_frac": f_alg / med[2] / 1e12 / F64_MFMA_PEAK_TF}
+
+    b_alg, f_alg = kernel_model("xc_sweep", xc, ngrid, nao)
+    abi = measure("dm")
+    occ = measure("occ")
     del ao, gr, w, solver
     torch.cuda.empty_cache()
-    b_alg, f_alg = kernel_model("xc_sweep", xc, ngrid, nao)
-    return {"workload": f"{workload}: ONE grid of {ngrid} points sharded over {world} GPU(s) ({n_loc} on rank 0), nao {nao}, {xc}",
-            "scaling": "strong", "ms_per_step": 1e3 * med[2], "sweep_ms": 1e3 * med[0], "allreduce_ms": 1e3 * med[1],
-            "allreduce_payload_bytes": 8 * (nao * nao + 1), "grid_points_per_sec": ngrid / med[2],
-            "steps": steps, "statistic": "median over steps of the max over ranks", "exc": exc,
-            "hbm_frac": b_alg / med[2] / 1e9 / HBM_PEAK_GBS, "mfma_frac": f_alg / med[2] / 1e12 / F64_MFMA_PEAK_TF}
+    res = {"workload": f"{workload}: ONE grid of {ngrid} points sharded over {world} GPU(s) ({n_loc} on rank 0), nao {nao}, nocc {nocc}, {xc}",
+           "scaling": "strong", "entry_point": "DFT_ComputeXCOccAsync (occupied orbitals, dm = cocc cocc^T: the extension a driver that holds C calls)",
+           "allreduce_payload_bytes": 8 * (nao * nao + 1), "steps": steps, "statistic": "median over steps of the max over ranks",
+           "fractions_note": "hbm_frac / mfma_frac price the time against SURVEY 8(d)'s algorithmic bytes and flops of the dm form (4 ngrid nao^2 + ...), "
+                             "whichever entry point ran: the occupied form executes fewer flops for the same result",
+           "abi_dm_entry": dict(abi, entry_point="DFT_ComputeXCAsync (full density matrix, the reference ABI's contraction)")}
+    res.update(occ)
+    return res
 
 
 def scf_sharded_leg(lib_path, dev, dist, backend, world, rank, workload="anthracene_b3lyp_def2tzvp", cycles=6, warmup=2):
@@ -444,7 +470,7 @@ def scf_sharded_leg(lib_path, dev, dist, backend, world, rank, workload="anthrac
     lo, hi = shard_bounds(ngrid, world, rank)
     plo, phi = vector_bounds(naux, world, rank)
     n_loc, nv_loc = hi - lo, phi - plo
-    dm, ao, gr, w = synth(max(n_loc, 16), nao, True, dev, SEED + 104729 * (rank + 1))
+    dm, ao, gr, w, _ = synth(max(n_loc, 16), nao, True, dev, SEED + 104729 * (rank + 1))
     g = torch.Generator(device=dev); g.manual_seed(SEED + 31 * (rank + 1))
     chol = torch.randn((max(nv_loc, 1), nao, nao), dtype=f64, device=dev, generator=g) * 1e-2
     solver = q.DFTSolverWrapper(lib_path, xc)
@@ -566,6 +592,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    coll_name = "RCCL" if args.backend == "nccl" else "gloo (host; rehearsal only)"
     strong = args.scaling == "strong"
     workload = args.workload or ("c33_b3lyp_def2svp" if strong else "benzene_gga_def2svp")
     xc, nao, ngrid_all = WORKLOADS[workload]
@@ -576,12 +603,13 @@ def main():
         total_points = ngrid_all
     else:
         ngrid, total_points = ngrid_all, world * ngrid_all
-    dm, ao, gr, w = synth(max(ngrid, 16), nao, xc != "LDA", dev, SEED + rank)   # dm identical on all ranks
+    dm, ao, gr, w, cocc = synth(max(ngrid, 16), nao, xc != "LDA", dev, SEED + rank)   # dm identical on all ranks
     if world > 1:
-        if args.backend == "nccl":
-            dist.broadcast(dm, 0)
-        else:
-            h = dm.cpu(); dist.broadcast(h, 0); dm.copy_(h)
+        for t_ in (dm, cocc):
+            if args.backend == "nccl":
+                dist.broadcast(t_, 0)
+            else:
+                h = t_.cpu(); dist.broadcast(h, 0); t_.copy_(h)
     solver = q.DFTSolverWrapper(lib_path, xc)
     out = torch.zeros(nao * nao + 1, dtype=torch.float64, device=dev)   # [Vxc | Exc]
     d_v, d_e = out[: nao * nao], out[nao * nao:]
@@ -598,6 +626,21 @@ def main():
         else:                                                           # rehearsal: gloo reduces on the host
             h = out.cpu(); dist.all_reduce(h); out.copy_(h)
         return float(d_e.item())                                        # device sync, like the ABI call
+
+    nocc = cocc.shape[1]
+
+    def step_occ():   # the same step through the extension entry point DFT_ComputeXCOcc (occupied orbitals, dm = cocc cocc^T)
+        if world == 1:
+            return solver.compute_xc_occ(ngrid, nao, nocc, cocc, ao, w, d_v, gr, dm)
+        if ngrid:
+            solver.compute_xc_occ_async(ngrid, nao, nocc, cocc, ao, w, d_v, d_e, gr, dm)
+        else:
+            out.zero_()
+        if args.backend == "nccl":
+            dist.all_reduce(out)
+        else:
+            h = out.cpu(); dist.all_reduce(h); out.copy_(h)
+        return float(d_e.item())
 
     def fence():
         if world > 1:
@@ -631,18 +674,36 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # per-kernel durations: HIP events recorded by the library on its own stream, same steps
-    kern = {}
-    if ngrid:
+    # the same K steps through DFT_ComputeXCOcc (same inputs, same barrier / synchronise bracket, max over ranks)
+    for _ in range(args.warmup):
+        exc_occ = step_occ()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        exc_occ = step_occ()
+    fence()
+    dt_occ = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt_occ], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_occ = float(tt.item())
+
+    # per-kernel durations: HIP events recorded by the library on its own stream, in a loop of its own (profile option on)
+    def kernel_times(call):
         solver.set_option("profile", 1)
         acc = {}
         for i in range(max(args.steps, 10)):
-            solver.compute_xc(ngrid, nao, dm, ao, w, d_v, gr)
+            call()
             if i % 10 == 9:   # events are recorded on every call; read every tenth so the calls stay back to back
                 for name, ms in solver.timings():
                     acc.setdefault(name, []).append(ms)
         solver.set_option("profile", 0)
-        kern = {k: float(np.mean(v)) for k, v in acc.items()}
+        return {k: float(np.mean(v)) for k, v in acc.items()}
+
+    kern, kern_occ = {}, {}
+    if ngrid:
+        kern = kernel_times(lambda: solver.compute_xc(ngrid, nao, dm, ao, w, d_v, gr))
+        kern_occ = kernel_times(lambda: solver.compute_xc_occ(ngrid, nao, nocc, cocc, ao, w, d_v, gr, dm))
 
     # ---- the headline line is complete here; everything below only adds members to it ---------------------------
     line = None
@@ -657,7 +718,9 @@ def main():
             roof = {"bound": "mfma", "achieved": f_all / t_step / 1e12, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": mfma_frac}
         roof.update({"scope": "whole DFT_ComputeXC call (all its kernels + the host's wait), algorithmic bytes/flops of SURVEY 8(d) / ms_per_step",
                      "hbm_frac": hbm_frac, "mfma_frac": mfma_frac, "alg_bytes": b_all, "alg_flops": f_all,
-                     "kernel_sum_ms": float(sum(kern.values()))})
+                     "kernel_sum_ms_profiled_loop": float(sum(kern.values())),
+                     "kernel_sum_note": "HIP events of a separate loop run with the library's profile option on (an event pair per kernel): "
+                                        "not the timed loop, so it may exceed ms_per_step by a few us"})
         tr = pmc_traffic(workload, list(kern))
         roof["traffic"] = float(sum(tr["per_kernel"].values())) if tr else None
         if tr:
@@ -676,9 +739,19 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{workload}: DFT_ComputeXC ({xc}) nao={nao} ngrid={ngrid_all}" + (" per GPU" if not strong else f" sharded over {world} GPU(s)") +
                                    ", synthetic AO/grid (SURVEY 8(d) recipe), inputs resident in HBM",
-                       "functional": xc, "nao": nao, "ngrid_per_gpu": ngrid,
-                       "sharding": "grid points" + ("" if world == 1 else f" x{world}, RCCL all-reduce of Vxc|Exc ({8 * (nao * nao + 1)} B)")},
+                       "functional": xc, "nao": nao, "nocc": nocc, "ngrid_per_gpu": ngrid,
+                       "entry_point": "DFT_ComputeXC (the reference ABI: full density matrix)" if world == 1 else "DFT_ComputeXCAsync (full density matrix) + all-reduce",
+                       "sharding": "grid points" + ("" if world == 1 else f" x{world}, {coll_name} all-reduce of Vxc|Exc ({8 * (nao * nao + 1)} B)")},
+            "backend": args.backend if world > 1 else None,
+            "world_size_seen": (dist.get_world_size() if world > 1 else 1), "device_count": ndev,
             "roofline": roof, "kernels_ms": kern, "exc": exc,
+            # the same steps through the extension that takes the occupied orbitals (what scf.HipBackend calls): same
+            # results, the density step does 4 nao nocc instead of 2 nao^2 flops per grid point
+            "occ_entry": {"entry_point": "DFT_ComputeXCOcc (occupied orbitals cocc (nao, nocc), dm = cocc cocc^T)" + ("" if world == 1 else " async + all-reduce"),
+                          "ms_per_step": 1e3 * dt_occ / args.steps, "value": total_points * args.steps / dt_occ, "unit": "grid-points/s",
+                          "exc": exc_occ, "exc_rel_diff_to_abi": abs(exc_occ - exc) / max(abs(exc), 1e-300), "kernels_ms": kern_occ,
+                          "hbm_frac": b_all / (dt_occ / args.steps) / 1e9 / HBM_PEAK_GBS,
+                          "note": "hbm_frac against the same algorithmic bytes as the ABI call; the occupied form reads the AO plane once"},
         }
 
     # The extra legs must never cost the headline: a watchdog thread ends the process after `args.legs_seconds` -- rank 0
@@ -687,18 +760,27 @@ def main():
     # inside HIP / RCCL (torch drops the GIL there).
     import threading
     printed = threading.Lock()
+    line_lock = threading.Lock()       # members are added under it; the dump takes a copy under it
+
+    def put(key, value):
+        if line is not None:
+            with line_lock:
+                line[key] = value
 
     def emit(note=None):
         if not printed.acquire(blocking=False):
             return
         if line is not None:
+            with line_lock:
+                snap = dict(line)
             if note:
-                line["legs_note"] = note
-            print(json.dumps(line), flush=True)
+                snap["legs_note"] = note
+            print(json.dumps(snap), flush=True)
 
     def expire():
-        emit(f"extra legs cut off after {args.legs_seconds:.0f} s: members present are complete, the others are missing")
-        os._exit(0)
+        # a leg that hangs is a failure the harness must see: the headline line is printed, then the process ends NON-ZERO
+        emit(f"extra legs cut off after {args.legs_seconds:.0f} s (exit code 3): members present are complete, the others are missing")
+        os._exit(3)
 
     dog = threading.Timer(args.legs_seconds, expire)
     dog.daemon = True
@@ -710,59 +792,60 @@ def main():
             ao = gr = None
             torch.cuda.empty_cache()
             strong5 = strong_leg(lib_path, dev, dist, args.backend, world, rank, "c33_b3lyp_def2svp")
-            if line is not None:
-                line["strong_config5"] = strong5
+            put("strong_config5", strong5)
             if world > 1:
                 scf_sh = scf_sharded_leg(lib_path, dev, dist, args.backend, world, rank)
-                if line is not None:
-                    line["scf_iteration_anthracene_sharded"] = scf_sh
+                put("scf_iteration_anthracene_sharded", scf_sh)
             scf_an = scf_real_sharded_leg(lib_path, dev, world, rank)
-            if line is not None:
-                line["scf_anthracene_def2svp_real"] = scf_an
+            put("scf_anthracene_def2svp_real", scf_an)
             if world == 1:
-                dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)   # the same inputs again for the legs below
-                line["ao_sweep"] = ao_sweep_leg(lib_path, dev)
+                dm, ao, gr, w, cocc = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)   # the same inputs again for the legs below
+                put("ao_sweep", ao_sweep_leg(lib_path, dev))
                 # ms/SCF-iter of the BASELINE metric = the driver's own loop on the real molecules (energies as checksums)
                 real = scf_real_leg(lib_path, dev)
-                line["scf_benzene_real"] = real
+                put("scf_benzene_real", real)
                 for key, src, what in (("scf_iteration", "dense_eri_auto", "dense ERI (the reference's formulation, dft.py:166,203)"),
                                        ("scf_iteration_factorised_j", "factorised_j_auto", "factorised J (Cholesky vectors, 1e-8)")):
                     r = real[src]
-                    line[key] = {"ms": r["ms_per_cycle"], "workload": real["workload"] + "; " + what, "statistic": real["statistic"],
+                    put(key, {"ms": r["ms_per_cycle"], "workload": real["workload"] + "; " + what, "statistic": real["statistic"],
                                  "parts_ms": {"xc": r["xc_ms"], "jk": r["jk_ms"], "host_eigen_diis_fock_transfers": r["ms_per_cycle"] - r["xc_ms"] - r["jk_ms"]},
                                  "cycles": r["cycles"], "converged": r["converged"], "E_tot": r["E_tot"], "eigensolver": r["eigensolver"],
-                                 "eigh_every_cycle_ms": real[src.replace("_auto", "_exact")]["ms_per_cycle"]}
+                                 "eigh_every_cycle_ms": real[src.replace("_auto", "_exact")]["ms_per_cycle"],
+                                 "xc_entry_point": "DFT_ComputeXCOcc (the driver holds cocc; scf.HipBackend default)",
+                                 "abi_xc_entry": real.get(src.replace("_auto", "_abi_xc"))})
                 # the same loop body with synthetic operands and eigh(F, S) EVERY cycle (round 1's legs, kept for comparison)
-                line["scf_iteration_synthetic"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev)
-                line["scf_iteration_synthetic_factorised_j"] = scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, eri="cholesky")
+                put("scf_iteration_synthetic", scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev))
+                put("scf_iteration_synthetic_factorised_j", scf_iteration_ms(solver, xc, nao, ngrid, dm, ao, gr, w, dev, eri="cholesky"))
                 del ao, gr
                 torch.cuda.empty_cache()
                 xa, na, ga = WORKLOADS["anthracene_b3lyp_def2tzvp"]
-                dm_a, ao_a, gr_a, w_a = synth(ga, na, True, dev, SEED)
-                line["scf_iteration_anthracene_synthetic"] = scf_iteration_ms(q.DFTSolverWrapper(lib_path, xa), xa, na, ga, dm_a, ao_a, gr_a, w_a, dev, iters=7)
+                dm_a, ao_a, gr_a, w_a, _ = synth(ga, na, True, dev, SEED)
+                put("scf_iteration_anthracene_synthetic", scf_iteration_ms(q.DFTSolverWrapper(lib_path, xa), xa, na, ga, dm_a, ao_a, gr_a, w_a, dev, iters=7))
                 del ao_a, gr_a
                 torch.cuda.empty_cache()
                 # BASELINE config 3 through the driver: Anthracene B3LYP in the def2-TZVP-shaped basis (nao 494; ~12 s of host
                 # integrals for its Cholesky vectors, hence last among the SCF legs)
                 an = scf_real_sharded_leg(lib_path, dev, 1, 0, basis_name="def2-tzvp", tol=1e-7)
-                line["scf_iteration_anthracene"] = dict(an, ms=an["ms_per_cycle"])
-                dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)
+                put("scf_iteration_anthracene", dict(an, ms=an["ms_per_cycle"]))
+                dm, ao, gr, w, cocc = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)
         if world == 1 and not args.no_k_build:
-            line["k_build"] = k_build_mfma(lib_path, dev)
+            put("k_build", k_build_mfma(lib_path, dev))
         if world == 1 and not args.no_cpu_baseline:
             if ao is None:
-                dm, ao, gr, w = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)
-            line["cpu_baseline"] = cpu_baseline(xc, dm, ao, gr, w, args.cpu_seconds)
+                dm, ao, gr, w, cocc = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)
+            put("cpu_baseline", cpu_baseline(xc, dm, ao, gr, w, args.cpu_seconds))
     except Exception as e:   # noqa: BLE001 -- whatever a leg raises, the measured headline is still printed
         note = f"an extra leg failed ({type(e).__name__}: {e}); members present are complete"
     dog.cancel()
     emit(note)
+    if note is not None:
+        # a leg raised: the headline line is out, the failure is visible to the harness through the exit code
+        # (with N > 1 the ranks may be out of step: no further collective, no clean shutdown)
+        sys.stdout.flush()
+        os._exit(4)
     if world > 1:
-        if note is None:
-            dist.barrier()
-            dist.destroy_process_group()
-        else:
-            os._exit(0)    # the ranks may be out of step: no further collective
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -43,11 +43,12 @@ class ShardedXC:
     tests inject a CPU closure to exercise the partition + collective under gloo.
     """
 
-    def __init__(self, nao, local_sweep, device, group=None):
+    def __init__(self, nao, local_sweep, device, group=None, collect_always=False):
         self.nao = nao
         self.local_sweep = local_sweep
         self.device = device
         self.group = group
+        self.collect_always = collect_always   # run the collective in a group of ONE rank too (the RCCL smoke test on a one-GPU box)
         self.buf = torch.zeros(nao * nao + 1, dtype=torch.float64, device=device)  # [Vxc | Exc]
 
     def compute_xc(self, dm):
@@ -55,7 +56,7 @@ class ShardedXC:
         exc, vxc = self.local_sweep(dm)
         self.buf[: self.nao * self.nao].copy_(vxc.reshape(-1))
         self.buf[self.nao * self.nao] = exc
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.collect_always):
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
         n2 = self.nao * self.nao
         return ShardResult(float(self.buf[n2].item()), self.buf[:n2].reshape(self.nao, self.nao))
@@ -91,12 +92,12 @@ class ReplicaSync:
     and since the stop decision is taken from the broadcast scalars every rank leaves the loop in the same
     cycle -- no rank is left blocking in the next all-reduce."""
 
-    def __init__(self, device, group=None):
-        self.device, self.group = torch.device(device), group
+    def __init__(self, device, group=None, collect_always=False):
+        self.device, self.group, self.collect_always = torch.device(device), group, collect_always
 
     def _bcast(self, flat):
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(self.group) == 1 and not self.collect_always):
             return flat
         if flat.is_cuda and dist.get_backend(self.group) == "gloo":   # rehearsal on one card: gloo moves host memory
             h = flat.cpu(); dist.broadcast(h, 0, group=self.group); flat.copy_(h)
@@ -139,8 +140,9 @@ class ShardedFock:
     (3 nao^2 + 1 doubles; BASELINE config 5, nao 1150: 31.7 MB).  `local_sweep(dm)` as in
     ShardedXC; `local_jk(dm, cocc)` returns this rank's (J_partial, K_partial or None)."""
 
-    def __init__(self, nao, local_sweep, local_jk, device, group=None):
+    def __init__(self, nao, local_sweep, local_jk, device, group=None, collect_always=False):
         self.nao, self.local_sweep, self.local_jk, self.group = nao, local_sweep, local_jk, group
+        self.collect_always = collect_always
         self.buf = torch.zeros(3 * nao * nao + 1, dtype=torch.float64, device=device)
 
     def compute(self, dm, cocc=None):
@@ -155,7 +157,7 @@ class ShardedFock:
         else:
             self.buf[2 * n2:3 * n2].zero_()
         self.buf[3 * n2] = exc
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.collect_always):
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
         m = lambda k: self.buf[k * n2:(k + 1) * n2].reshape(self.nao, self.nao)
         return FockParts(float(self.buf[3 * n2].item()), m(0), m(1), m(2))

@@ -198,3 +198,36 @@ def test_async_entry_point_on_a_caller_stream(dev):
     sv.set_stream(0)
     e3 = sv.compute_xc(2000, nao, d_dm, d_ao, d_w, d_v, d_gr)
     assert e3 == e_sync
+
+
+@pytest.mark.parametrize("fuse_finish", [0, 1])
+def test_vxc_is_complete_for_another_stream_when_the_synchronous_call_returns(dev, fuse_finish):
+    """The reference's compute_xc ends with a blocking copy + cudaFree (dft_solver.cu:575-582): on return d_vxc is complete
+    for ANY consumer.  Default here: Exc is published by a finishing kernel that stream order starts after the whole
+    sweep, so the same holds -- the solver runs on a side stream, a second, non-blocking stream copies d_vxc right after
+    the call returns, no synchronisation in between.  With fuse_finish = 1 (the reduce kernel publishes Exc itself) the
+    guarantee needs option strict_sync = 1, which is what this test sets for that case."""
+    ngrid, nao = 143556, 114
+    g = torch.Generator(device=dev); g.manual_seed(12)
+    ao = 0.4 * torch.randn((ngrid, nao), dtype=torch.float64, device=dev, generator=g)
+    gr = 0.3 * torch.randn((3, ngrid, nao), dtype=torch.float64, device=dev, generator=g)
+    w = 0.05 * torch.rand((ngrid,), dtype=torch.float64, device=dev, generator=g)
+    c = torch.randn((nao, 21), dtype=torch.float64, device=dev, generator=g)
+    dm = (c @ c.T).contiguous()
+    sv = _solver(1, fuse_finish=fuse_finish, strict_sync=fuse_finish)
+    v_ref = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
+    e_ref = sv.compute_xc(ngrid, nao, dm, ao, w, v_ref, gr)
+    torch.cuda.synchronize()
+    side, other = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    sv.set_stream(side.cuda_stream)
+    host = torch.empty((nao, nao), dtype=torch.float64).pin_memory()
+    for rep in range(20):
+        d_v = torch.full((nao, nao), float("nan"), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        e = sv.compute_xc(ngrid, nao, dm, ao, w, d_v, gr)            # returns when Exc has been published
+        with torch.cuda.stream(other):                               # a stream that is NOT ordered behind the solver's
+            host.copy_(d_v, non_blocking=True)
+        other.synchronize()
+        assert e == e_ref
+        assert torch.equal(host, v_ref.cpu()), f"repetition {rep}: Vxc read on another stream right after the call differs"
+    sv.set_stream(0)
