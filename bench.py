@@ -830,6 +830,7 @@ def main():
                 dm, ao, gr, w, cocc = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)
         if world == 1 and not args.no_k_build:
             put("k_build", k_build_mfma(lib_path, dev))
+            put("k_build_nocc60", k_build_mfma(lib_path, dev, nocc=60))   # the 49-64 orbital tile of the half transform (MI = 4: two workgroups per CU since round 3)
         if world == 1 and not args.no_cpu_baseline:
             if ao is None:
                 dm, ao, gr, w, cocc = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)

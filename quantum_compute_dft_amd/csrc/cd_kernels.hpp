@@ -45,9 +45,11 @@ constexpr int CD_BN = 256, CD_BK = 16, CD_LDB = CD_BN + 16; // 272 = 16 (mod 32)
 // vector/LDS/VMEM (4 scalar) instructions per 64 cycles (tools/coissue_probe*.hip), so what sets the pace is
 // the NON-MFMA instruction count per MFMA: the 16 x 32 wave tile needed 5 LDS reads per 6 MFMAs and ~100
 // other instructions per 24-MFMA stage (57 % MFMA-busy, profiles/r01_pmc_kbuild.json); this one needs 7 reads
-// per 12 MFMAs and ~45 per stage, and at 45 KB of LDS and <= 168 VGPRs (launch bound) THREE workgroups share a CU.
+// per 12 MFMAs and ~45 per stage, and at 45 KB of LDS and <= 168 VGPRs (launch bound) THREE workgroups share a CU
+// for MI <= 3 (nocc <= 48); MI = 4 (nocc 49-64: 64 accumulator VGPRs more) does not fit 168 registers -- it spilled
+// 10-75 of them under that bound (round 2) -- and runs two workgroups per CU.
 template <int WGM, int MI, bool VECA, bool VECB, bool DOT = false, int NW = 8, int BK_ = 0, int NJ_ = 0>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && BK_ == 8) ? 3 : 2) void k_gemm_tn(long G, int M, int N, int lda, int ldb,
+__global__ __launch_bounds__(64 * NW, (NW == 4 && BK_ == 8 && MI <= 3) ? 3 : 2) void k_gemm_tn(long G, int M, int N, int lda, int ldb,
                                                            const double *__restrict__ A, long strideA,
                                                            const double *__restrict__ B, long strideB,
                                                            long chunk, int nB, int npair, int split,

@@ -65,10 +65,8 @@ __device__ __forceinline__ void buf_load_pair(__amdgpu_buffer_rsrc_t r, unsigned
         a = __hiloint2double((int)v[1], (int)v[0]);
         b = __hiloint2double((int)v[3], (int)v[2]);
     } else { // odd nao or 8-byte aligned base: two 8-byte loads
-        const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM, soff, 0);
-        const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM + 8, soff, 0);
-        a = __hiloint2double((int)lo[1], (int)lo[0]);
-        b = __hiloint2double((int)hi[1], (int)hi[0]);
+        a = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM, soff, 0));
+        b = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM + 8, soff, 0));
     }
 }
 // JN column groups of GW bytes each (GW = 256: 16 lanes per grid row, 512: 32 lanes per row)
@@ -82,8 +80,7 @@ __device__ __forceinline__ void buf_load_row(__amdgpu_buffer_rsrc_t r, unsigned 
 }
 __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return __hiloint2double((int)v[1], (int)v[0]);
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
 // Sum over the 16 lanes of a DPP row with row rotations: pure VALU, no LDS traffic (the
 // ds_bpermute butterfly cost 21 us of a 147 us kernel).  Every lane ends with the total.
@@ -110,8 +107,7 @@ __device__ __forceinline__ double2 buf_load_d2(__amdgpu_buffer_rsrc_t r, unsigne
 }
 __device__ __forceinline__ double buf_load_d1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return __hiloint2double((int)v[1], (int)v[0]);
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
 // two consecutive doubles at byte offset voff+soff; VEC = 16-byte aligned rows (nao even)
 template <bool VEC>

@@ -83,3 +83,30 @@ def test_no_gpu_means_loud_failure(libpath):
     w = q.DFTSolverWrapper(libpath, "LDA")
     with pytest.raises(RuntimeError):
         w.compute_xc(8, 2, 0, 0, 0, 0)
+
+
+def test_spill_guard_of_the_build():
+    """build.py reads every kernel's resource usage from the compiler's report and fails the build when a product kernel
+    spills; the report of the library in the tree must be clean, and the checker must catch a spill when shown one."""
+    import json
+    from quantum_compute_dft_amd import build
+    q.build_library()
+    res = json.load(open(build.RESOURCES_PATH))
+    assert len(res) > 200                                             # every instantiation is listed
+    assert any("k_rho_occ_rs" in k for k in res) and any("k_gemm_tn" in k for k in res)
+    assert build.check_spills(res) == []
+    spilled = {k: v for k, v in res.items() if v["vgpr_spill"] or v["scratch"]}
+    for k in spilled:                                                  # whatever spills is a validation kernel or allow-listed with a reason
+        assert any(v in k for v in build.VALIDATION_KERNELS) or any(k.startswith(a) for a in build.SPILL_ALLOW), k
+    fake = {"void qcdft::k_gemm_tn<1, 4, true, false, true, 4, 8, 4>(long)": dict(vgprs=168, agprs=0, sgprs=90, vgpr_spill=75, sgpr_spill=0,
+                                                                               scratch=140, occupancy=3, lds=0)}
+    bad = build.check_spills(fake)
+    assert len(bad) == 1 and "75 VGPRs spilled" in bad[0]
+    text = ("x.hpp:1:1: remark: Function Name: _Zfoo [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hpp:1:1: remark:     TotalSGPRs: 20 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hpp:1:1: remark:     VGPRs: 77 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hpp:1:1: remark:     ScratchSize [bytes/lane]: 16 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hpp:1:1: remark:     Occupancy [waves/SIMD]: 6 [-Rpass-analysis=kernel-resource-usage]\n"
+            "x.hpp:1:1: remark:     VGPRs Spill: 4 [-Rpass-analysis=kernel-resource-usage]\n")
+    parsed = build.parse_resource_usage(text)
+    assert parsed["_Zfoo"]["vgprs"] == 77 and parsed["_Zfoo"]["vgpr_spill"] == 4 and parsed["_Zfoo"]["scratch"] == 16 and parsed["_Zfoo"]["occupancy"] == 6
