@@ -18,7 +18,10 @@ OccPlan occ_plan(int nao, int nocc, bool gga)
     p.nch = (nao + OC_KC - 1) / OC_KC;
     // all of C in LDS (row-shared kernel) when two workgroups still share a CU (160 KB of LDS)
     p.resident = p.npass == 1 && p.nto <= 4 && occ_rs_lds_bytes(p.nto, p.nch) <= 80 * 1024;
+    // streamed kernels: four-wave workgroups (two per CU) up to 64 orbitals per pass -- eight waves sharing one stream of C
+    // chunks halve its L2 traffic but march in lockstep: 961 against 928 us at the Anthracene/def2-TZVP shape
     p.nw = (p.resident || p.nto <= 4) ? 4 : 8;
+    if (const char *e = getenv("QCDFT_OCC_NW")) p.nw = p.resident ? 4 : (atoi(e) == 4 && p.nto <= 4 ? 4 : 8);   // tools/occ_time.py
     p.lds_bytes = p.resident ? occ_rs_lds_bytes(p.nto, p.nch) : occ_lds_bytes(p.nto, p.nw, false, p.nch, p.npass);
     p.cp_doubles = (size_t)p.npass * p.nch * OC_KC * 16 * p.nto;
     const int NT = (nao + 15) / 16;
@@ -71,7 +74,8 @@ hipError_t launch_nto(hipStream_t st, int num_cu, const OccPlan &p, long ngrid, 
             if (p.nch > 4) return launch(k_rho_occ_rs<NTO, GRAD, VEC, true>, allowed4);   // more than one chunk per wave
             return launch(k_rho_occ_rs<NTO, GRAD, VEC, false>, allowed1);
         }
-        return launch_one<NTO, 4, GRAD, VEC, false, 1>(st, (unsigned)nrb, p.lds_bytes, ngrid, nao, p.nch, p.npass, ao, gx, gy, gz, cp, rho, grad, sigma);
+        if (p.nw == 4) return launch_one<NTO, 4, GRAD, VEC, false, 1>(st, (unsigned)nrb, p.lds_bytes, ngrid, nao, p.nch, p.npass, ao, gx, gy, gz, cp, rho, grad, sigma);
+        return launch_one<NTO, 8, GRAD, VEC, false, 1>(st, (unsigned)nrb, p.lds_bytes, ngrid, nao, p.nch, p.npass, ao, gx, gy, gz, cp, rho, grad, sigma);
     } else {
         return launch_one<NTO, 8, GRAD, VEC, false, 1>(st, (unsigned)nrb, p.lds_bytes, ngrid, nao, p.nch, p.npass, ao, gx, gy, gz, cp, rho, grad, sigma);
     }
