@@ -248,6 +248,8 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
             const double eff = (double)wgs / (double)(rounds * s->num_cu);
             if (eff > best + 1e-9) { best = eff; per_xcd = c; }
         }
+        // a chunk of one plane stays below 4 GiB: k_vxc_big addresses it through one buffer descriptor
+        while ((double)((ngrid + 8 * per_xcd - 1) / (8 * per_xcd) + BG_BK) * nao * 8.0 >= 4294967296.0) ++per_xcd;
         nslab = (int)(8 * per_xcd);
         chunk = (ngrid + nslab - 1) / nslab;
         chunk = ((chunk + BG_BK - 1) / BG_BK) * BG_BK;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_rho_big(long ngrid, int nao, 
         __syncthreads();
         for (int kc = 0; kc < nkc; ++kc) {
             const int buf = kc & 1;
-            if (kc + 1 < nkc) fetch(kc + 1);
+            fetch(kc + 1); // unconditional (see k_vxc_big): past the last k-chunk the operands are out of range / masked to zero and never used
             const double *A = As + buf * ASZ + (wm * 64 + li) * RB_LDA + lk;
             const double *B = Bs + buf * BSZ + lk * RB_LDB + wn * 32 + li;
 #pragma unroll
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_rho_big(long ngrid, int nao, 
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
             }
-            if (kc + 1 < nkc) stash(buf ^ 1);
+            stash(buf ^ 1);
             __syncthreads();
         }
 
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void k_rho_big64(long ngrid, int nao, int N
         __syncthreads();
         for (int kc = 0; kc < nkc; ++kc) {
             const int buf = kc & 1;
-            if (kc + 1 < nkc) fetch(kc + 1);
+            fetch(kc + 1); // unconditional (see k_vxc_big)
             const double *A = As + buf * ASZ + (wm * 32 + li) * R6_LDA + lk;
             const double *B = Bs + buf * BSZ + lk * RB_LDB + wn * 64 + li;
 #pragma unroll
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void k_rho_big64(long ngrid, int nao, int N
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
             }
-            if (kc + 1 < nkc) stash(buf ^ 1);
+            stash(buf ^ 1);
             __syncthreads();
         }
 
@@ -433,29 +433,39 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_vxc_big(long ngrid, int nao, 
 
         double2 q0[2], q1[2], q2[2], q3[2], pp[4];
         double k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+        // ONE descriptor per plane and per coefficient row for the whole chunk (rows >= ghi must not contribute: the
+        // range ends at ghi), the stage selected by the SGPR offset of the loads; a stage past the end passes the
+        // chunk size -- every lane out of range, no traffic, the loads still count in vmcnt -- so the fetch is issued
+        // UNCONDITIONALLY.  (With `if (st + 1 < nst) fetch(st + 1)` the loaded registers reached the loop header
+        // through a merge, the compiler copied them there and waited for 12 of the 16 loads of the NEXT stage before
+        // this stage's first MFMA: the prefetch was mostly serialised, 65 % MFMA-busy, profiles/r03_pmc_sweep.json.)
+        // The host keeps a chunk of a plane below 4 GiB.
+        const long crow = ghi - glo;
+        const __amdgpu_buffer_rsrc_t r0 = plane_rsrc(ao + glo * nao, crow * nao);
+        const __amdgpu_buffer_rsrc_t r1 = plane_rsrc((GRAD ? gx : ao) + glo * nao, crow * nao);
+        const __amdgpu_buffer_rsrc_t r2 = plane_rsrc((GRAD ? gy : ao) + glo * nao, crow * nao);
+        const __amdgpu_buffer_rsrc_t r3 = plane_rsrc((GRAD ? gz : ao) + glo * nao, crow * nao);
+        const __amdgpu_buffer_rsrc_t d0 = plane_rsrc(c0 + glo, crow), d1 = plane_rsrc((GRAD ? c1 : c0) + glo, crow),
+                                     d2 = plane_rsrc((GRAD ? c2 : c0) + glo, crow), d3 = plane_rsrc((GRAD ? c3 : c0) + glo, crow);
+        const unsigned p_end = (unsigned)(crow * nao * 8), k_end = (unsigned)(crow * 8);
+        const unsigned p_step = (unsigned)(BG_BK * nao) * 8u, k_step = BG_BK * 8u;
         auto fetch = [&](int st) {
-            const long row0 = glo + (long)st * BG_BK; // < ghi <= ngrid
-            const long e0 = row0 * nao;
-            // the chunk ends at ghi: rows >= ghi must not contribute -> descriptor ends at ghi
-            const long pend = ghi * (long)nao;
-            const __amdgpu_buffer_rsrc_t r0 = plane_tile_rsrc(ao, pend, e0);
-            k0 = buf_load_d1(plane_tile_rsrc(c0, ghi, row0), k_voff, 0);
+            const bool live = st < nst;
+            const unsigned so = live ? (unsigned)st * p_step : p_end, ko = live ? (unsigned)st * k_step : k_end;
+            k0 = buf_load_d1(d0, k_voff, ko);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) q0[h] = buf_load_pair2<VEC>(r0, q_voff + 16 * h, 0);
+            for (int h = 0; h < 2; ++h) q0[h] = buf_load_pair2<VEC>(r0, q_voff + 16 * h, so);
 #pragma unroll
-            for (int h = 0; h < 4; ++h) pp[h] = buf_load_pair2<VEC>(r0, p_voff + 16 * h, 0);
+            for (int h = 0; h < 4; ++h) pp[h] = buf_load_pair2<VEC>(r0, p_voff + 16 * h, so);
             if (GRAD) {
-                const __amdgpu_buffer_rsrc_t r1 = plane_tile_rsrc(gx, pend, e0);
-                const __amdgpu_buffer_rsrc_t r2 = plane_tile_rsrc(gy, pend, e0);
-                const __amdgpu_buffer_rsrc_t r3 = plane_tile_rsrc(gz, pend, e0);
-                k1 = buf_load_d1(plane_tile_rsrc(c1, ghi, row0), k_voff, 0);
-                k2 = buf_load_d1(plane_tile_rsrc(c2, ghi, row0), k_voff, 0);
-                k3 = buf_load_d1(plane_tile_rsrc(c3, ghi, row0), k_voff, 0);
+                k1 = buf_load_d1(d1, k_voff, ko);
+                k2 = buf_load_d1(d2, k_voff, ko);
+                k3 = buf_load_d1(d3, k_voff, ko);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    q1[h] = buf_load_pair2<VEC>(r1, q_voff + 16 * h, 0);
-                    q2[h] = buf_load_pair2<VEC>(r2, q_voff + 16 * h, 0);
-                    q3[h] = buf_load_pair2<VEC>(r3, q_voff + 16 * h, 0);
+                    q1[h] = buf_load_pair2<VEC>(r1, q_voff + 16 * h, so);
+                    q2[h] = buf_load_pair2<VEC>(r2, q_voff + 16 * h, so);
+                    q3[h] = buf_load_pair2<VEC>(r3, q_voff + 16 * h, so);
                 }
             }
         };
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_vxc_big(long ngrid, int nao, 
         __syncthreads();
         for (int st = 0; st < nst; ++st) {
             const int buf = st & 1;
-            if (st + 1 < nst) fetch(st + 1);
+            fetch(st + 1);
             const double *Q = Qs + buf * QSZ + lk * BG_LDQ + wm * 64 + li;
             const double *P = Ps + buf * PSZ + lk * BG_LDB + wn * 64 + li;
 #pragma unroll
@@ -495,7 +505,7 @@ __global__ __launch_bounds__(BG_THREADS, 2) void k_vxc_big(long ngrid, int nao, 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = mfma_f64(af[i], bf[j], acc[i][j]);
             }
-            if (st + 1 < nst) stash(buf ^ 1);
+            stash(buf ^ 1); // behind the last stage: zeros into the idle buffer
             __syncthreads();
         }
     }
