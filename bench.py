@@ -386,7 +386,7 @@ def scf_real_sharded_leg(lib_path, dev, world, rank, molecule="Anthracene", func
     The converged energy is the checksum (-539.14207342 Ha on one GPU)."""
     from quantum_compute_dft_amd import inputs, scf
     t0 = time.perf_counter()
-    inp = inputs.build(molecule, basis_name, 3, device=dev, verbose=False, eri_mode="cholesky", chol_tol=tol)
+    inp = inputs.build(molecule, basis_name, 3, device=dev, verbose=False, eri_mode="cholesky", chol_tol=tol, rank=rank, world=world)
     t_build = time.perf_counter() - t0
     abi = None
     if world == 1:   # the same SCF with the reference ABI's DFT_ComputeXC (full density matrix) in the sweep, beside the default
@@ -397,8 +397,9 @@ def scf_real_sharded_leg(lib_path, dev, world, rank, molecule="Anthracene", func
     be = scf.HipBackend(inp, functional, lib_path, rank=rank, world=world, device=dev)
     r = scf.run_scf(inp, be, functional, log=None)
     out = {"xc_entry_point": "DFT_ComputeXCOcc (occupied orbitals; scf.HipBackend default)", "abi_xc_entry": abi,
-           "workload": f"{molecule} {functional}/{basis_name}: nao {inp.shells.nao}, {inp.grids.size} grid points, {inp.chol.shape[0]} Cholesky vectors "
-                       f"({tol:g}), sharded over {world} GPU(s); inputs built on every rank in {t_build:.1f} s (not timed)",
+           "workload": f"{molecule} {functional}/{basis_name}: nao {inp.shells.nao}, {inp.grids.size} grid points, {(inp.chol_range[2] if inp.chol_range else inp.chol.shape[0])} Cholesky vectors "
+                       f"({tol:g}), sharded over {world} GPU(s); inputs built in {t_build:.1f} s (not timed; the Cholesky factorisation on rank 0 alone, "
+                       f"vector slices sent to the ranks)",
            "scaling": "strong", "ms_per_cycle": r["iter_ms"], "xc_ms": r["xc_ms"], "jk_ms": r["jk_ms"], "cycles": r["cycles"],
            "converged": bool(r["converged"]), "E_tot": r["E_tot"], "total_ms": 1e3 * r["total_time"],
            "device_resident": bool(be.device_resident),

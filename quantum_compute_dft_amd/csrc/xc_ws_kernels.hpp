@@ -42,6 +42,7 @@ __device__ unsigned long long g_stamps[256 * 8 * 4];
 constexpr int WS_ROWS = 16;      // grid points per sub-tile
 constexpr int WS_THREADS = 512;  // 4 MFMA waves + 4 loader waves
 constexpr int WS_RING = 4;       // LDS ring depth (static stage index under 4x unrolling)
+constexpr int WS_OT = 16;        // sub-tiles of density results per burst of stores (k_rho_ws)
 
 template <int NT> struct WsCfg {
     static constexpr int NCOL = 16 * NT;                      // padded AO columns
@@ -303,6 +304,10 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
     constexpr int ATILE = WS_ROWS * C::LDA, XTILE = WS_ROWS * C::LDX;
     __shared__ double As[WS_RING * ATILE];
     __shared__ double Xs[2 * XTILE];
+    // Results leave in BURSTS: rho / grad rho of WS_OT sub-tiles are collected here and written by the loader waves in
+    // one go (40 bytes per grid row, 1 % of the traffic -- but stored sub-tile by sub-tile the trickle of writes keeps
+    // turning the HBM channels around under the read stream: 10 us of 85 in tools/stream_pattern_probe4.hip).
+    __shared__ double Ob[(WS_OT + 1) * WS_ROWS * 4];
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -401,6 +406,25 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
         if (GRAD) issue_grad(1, (unsigned)nloc);
         __builtin_amdgcn_sched_barrier(0);
 
+        long flushed = 0;
+        auto flush = [&](long j0, long j1) {
+            const long j = j0 + (lt >> 4);
+            const int r = lt & 15;
+            if (j < j1 && j < nloc) {
+                const long g = (long)ws_tile((unsigned)ntile, blockIdx.x, (unsigned)j, gridDim.x, rev) * WS_ROWS + r;
+                if (g < ngrid) {
+                    const double *o = Ob + ((j % (WS_OT + 1)) * WS_ROWS + r) * 4;
+                    rho[g] = o[0];
+                    if (GRAD) {
+                        const double ax = o[1], ay = o[2], az = o[3];
+                        grad[3 * g + 0] = ax;
+                        grad[3 * g + 1] = ay;
+                        grad[3 * g + 2] = az;
+                        sigma[g] = ax * ax + ay * ay + az * az;
+                    }
+                }
+            }
+        };
         for (long base = 0; base < nstep; base += WS_RING) {
 #pragma unroll
             for (int u = 0; u < WS_RING; ++u) {
@@ -447,22 +471,25 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
                         s2 = row16_sum(s2);
                         s3 = row16_sum(s3);
                     }
-                    if (seg == 0 && row_ok) {
-                        rho[g] = s0;
-                        if (GRAD) {
-                            const double ax = 2.0 * s1, ay = 2.0 * s2, az = 2.0 * s3;
-                            grad[3 * g + 0] = ax;
-                            grad[3 * g + 1] = ay;
-                            grad[3 * g + 2] = az;
-                            sigma[g] = ax * ax + ay * ay + az * az;
-                        }
+                    (void)row_ok;
+                    if (seg == 0 && in_range) { // slot of sub-tile step-2 in the result ring
+                        double *o = Ob + (((step - 2) % (WS_OT + 1)) * WS_ROWS + row) * 4;
+                        o[0] = s0;
+                        if (GRAD) { o[1] = 2.0 * s1; o[2] = 2.0 * s2; o[3] = 2.0 * s3; }
                     }
+                }
+                // the results of sub-tiles [flushed, step-2) are complete (written before the previous barrier):
+                // one burst per WS_OT of them, thread = (sub-tile, row)
+                if (step - 2 - flushed == WS_OT) {
+                    flush(flushed, step - 2);
+                    flushed = step - 2;
                 }
                 // (c) gradients of sub-tile `step` into the set just freed (consumed at step+2)
                 if (GRAD) issue_grad(set, (unsigned)step);
                 __syncthreads();
             }
         }
+        flush(flushed, nloc); // the rest (at most WS_OT sub-tiles; the loop's last barrier made them visible)
     }
 }
 

@@ -75,7 +75,7 @@ def main(argv=None):
         from . import basis as _basis
         _nao = _basis.build_shells(*_basis.parse_xyz(atom_path), args.basis).nao
         args.eri = "dense" if 8.0 * _nao ** 4 <= 8.0e9 else "cholesky"
-    inp = inputs.build(atom_path, args.basis, args.grid_level, device=device, eri_mode=args.eri, chol_tol=args.chol_tol)
+    inp = inputs.build(atom_path, args.basis, args.grid_level, device=device, eri_mode=args.eri, chol_tol=args.chol_tol, rank=rank, world=world)
     print(f"System Info: NAO={inp.shells.nao}, Grid={inp.grids.size}, Occupied={inp.nocc}")
     print(f"Calculating AO Gradients ({args.functional} mode)..." if args.functional != "LDA" else "Skipping AO Gradients (LDA mode).")
     print("Moving data to GPU...")

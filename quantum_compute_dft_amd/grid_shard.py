@@ -85,6 +85,35 @@ def eri_row_bounds(nao, world_size, rank):
     return i_lo * nao, i_hi * nao
 
 
+def scatter_vectors(L, nao, device, world_size, rank, group=None):
+    """Rank 0 holds the Cholesky vectors L (naux, nao, nao) (torch tensor on any device, or numpy); every rank receives
+    its slice vector_bounds(naux, world, rank) as a tensor on `device` -- the factorisation runs ONCE per node (rank 0,
+    on the whole node's CPU allowance) instead of once per rank on 1/N of the cores.  Returns (slice, naux).
+    Point-to-point sends of the slices (no rank ever holds more than rank 0 already does); under gloo the payload goes
+    through host memory."""
+    import numpy as np
+    import torch.distributed as dist
+    dev = torch.device(device)
+    meta = [int(L.shape[0]) if rank == 0 else None]
+    dist.broadcast_object_list(meta, src=0, group=group)
+    naux = meta[0]
+    host = dist.get_backend(group) == "gloo"
+    if rank == 0:
+        Lt = L if torch.is_tensor(L) else torch.from_numpy(np.ascontiguousarray(L))
+        for r in range(1, world_size):
+            lo, hi = vector_bounds(naux, world_size, r)
+            if hi > lo:
+                part = Lt[lo:hi].contiguous()
+                dist.send(part.cpu() if host else part.to(dev), dst=r, group=group)
+        lo, hi = vector_bounds(naux, world_size, 0)
+        return Lt[lo:hi].to(dev).contiguous(), naux
+    lo, hi = vector_bounds(naux, world_size, rank)
+    buf = torch.empty((hi - lo, nao, nao), dtype=torch.float64, device="cpu" if host else dev)
+    if hi > lo:
+        dist.recv(buf, src=0, group=group)
+    return buf.to(dev), naux
+
+
 class ReplicaSync:
     """Rank 0 is authoritative for the small replicated state of the SCF loop (dm, cocc, the convergence
     scalars): it alone runs DIIS + eigh and every other rank receives the result in ONE broadcast per cycle.

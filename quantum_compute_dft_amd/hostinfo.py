@@ -3,9 +3,11 @@ import contextlib
 import os
 
 
-def host_cpu_share(cap=16):
+def host_cpu_share(cap=16, whole_node=False):
     """CPUs this process may really use: affinity mask, cgroup quota, capped (16 = the GPU box's
-    share for one GPU); os.cpu_count() reports the whole host (256 there)."""
+    share for one GPU); os.cpu_count() reports the whole host (256 there).  `whole_node`: the allowance of ALL
+    the node's ranks together (cap x LOCAL_WORLD_SIZE) -- for a phase in which one rank works and the others wait
+    (the Cholesky factorisation of the ERI, inputs.build)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -16,10 +18,12 @@ def host_cpu_share(cap=16):
     # ranks of one node (torch.distributed.run exports LOCAL_WORLD_SIZE) share that allowance: without the division
     # N ranks start N x share threads on the same cores (integrals, LAPACK) and slow each other down
     try:
-        n = max(1, n // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+        lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     except ValueError:
-        pass
-    return max(1, min(n, cap))
+        lws = 1
+    if whole_node:
+        return max(1, min(n, cap * lws))
+    return max(1, min(max(1, n // lws), cap))
 
 
 def blas_threads(n=None):

@@ -27,12 +27,16 @@ class SCFInputs:
     nocc: int
     nelec: int
     chol: np.ndarray = None  # (naux, nao, nao) Cholesky vectors of the ERI (eri_mode='cholesky')
+    chol_range: tuple = None  # (lo, hi, naux): `chol` is only THIS rank's slice of the naux vectors (build(..., world > 1))
 
 
 def build(atom_path, basis_name="sto-3g", grid_level=3, device="cpu", verbose=True, eri_mode="dense",
-          chol_tol=1e-9):
+          chol_tol=1e-9, rank=0, world=1, group=None):
     """grid.py:42-67.  `atom_path`: an .xyz file (or a molecule name resolved in data/).
-    eri_mode "dense": the (nao^4) tensor of grid.py:65; "cholesky": pivoted Cholesky vectors only."""
+    eri_mode "dense": the (nao^4) tensor of grid.py:65; "cholesky": pivoted Cholesky vectors only.
+    world > 1 (torch.distributed initialised): the Cholesky factorisation -- the one expensive step, host integral columns
+    + device algebra -- runs on rank 0 ALONE, on the whole node's CPU allowance while the other ranks wait, and every
+    rank receives only its slice of the vectors (grid_shard.scatter_vectors); `chol_range` records the slice."""
     if not os.path.exists(atom_path):
         cand = os.path.join(DATA_DIR, atom_path if atom_path.endswith(".xyz") else atom_path + ".xyz")
         if os.path.exists(cand):
@@ -51,18 +55,35 @@ def build(atom_path, basis_name="sto-3g", grid_level=3, device="cpu", verbose=Tr
     if verbose:
         print(f"Number of grid points for integration: {grids.size}")
     S, T, V = integrals.int1e(shells, symbols, xyz)
-    eri = chol = None
+    eri = chol = chol_range = None
     if eri_mode == "dense":
         eri = integrals.int2e(shells)
     elif eri_mode == "cholesky":
         from .cholesky import cholesky_eri
         import time
         t0 = time.time()
-        chol = cholesky_eri(shells, tol=chol_tol, device=device)   # on a GPU: the factorisation's algebra and the vectors stay there
+        if world > 1:
+            import torch.distributed as dist
+            from .grid_shard import scatter_vectors, vector_bounds
+            from .hostinfo import host_cpu_share
+            full = None
+            if rank == 0:
+                integrals.set_threads(host_cpu_share(whole_node=True))    # the other ranks are waiting in the scatter below
+                try:
+                    full = cholesky_eri(shells, tol=chol_tol, device=device)
+                finally:
+                    integrals.set_threads(host_cpu_share())
+            chol, naux = scatter_vectors(full, shells.nao, device, world, rank, group)
+            del full
+            chol_range = (*vector_bounds(naux, world, rank), naux)
+            if not str(device).startswith("cuda"):
+                chol = chol.numpy()
+        else:
+            chol = cholesky_eri(shells, tol=chol_tol, device=device)   # on a GPU: the factorisation's algebra and the vectors stay there
         if verbose:
             where = "integral columns on the host, algebra and vectors on the device" if str(device).startswith("cuda") else "on the host"
             print(f"Cholesky vectors of the ERI: {chol.shape[0]} (threshold {chol_tol:g}, {time.time() - t0:.1f} s; {where})")
     else:
         raise ValueError(f"eri_mode {eri_mode!r}: expected 'dense' or 'cholesky'")
     return SCFInputs(symbols, xyz, shells, grids, S, T, V, T + V, eri,
-                     integrals.energy_nuc(symbols, xyz), nocc, nelec, chol)
+                     integrals.energy_nuc(symbols, xyz), nocc, nelec, chol, chol_range)

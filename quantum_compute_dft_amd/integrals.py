@@ -77,6 +77,11 @@ def _args(sh):
     return keep, ptrs
 
 
+def set_threads(n):
+    """Worker threads of the integral engine's OpenMP regions (default: this rank's CPU share, hostinfo.py)."""
+    _load().qc_set_threads(int(n))
+
+
 def int1e(shells, symbols, atom_xyz):
     """(S, T, V) as (nao, nao) arrays; V is the nuclear-attraction matrix (negative)."""
     keep, p = _args(shells)

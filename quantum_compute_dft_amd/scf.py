@@ -366,8 +366,11 @@ class HipBackend:
             if rhi > rlo:
                 self.d_eri = torch.as_tensor(np.ascontiguousarray(inp.eri.reshape(nao * nao, nao * nao)[rlo:rhi]), dtype=f64, device=self.dev)
         else:  # factorised J/K (DFT_ComputeJKFactorized): Cholesky vectors stay resident instead of the ERI
-            plo, phi = vector_bounds(inp.chol.shape[0], world, rank)
-            self.d_chol = torch.as_tensor(inp.chol[plo:phi], dtype=f64, device=self.dev)
+            if getattr(inp, "chol_range", None) is not None:      # inputs.build(world > 1) handed over this rank's slice only
+                self.d_chol = torch.as_tensor(inp.chol, dtype=f64, device=self.dev)
+            else:
+                plo, phi = vector_bounds(inp.chol.shape[0], world, rank)
+                self.d_chol = torch.as_tensor(inp.chol[plo:phi], dtype=f64, device=self.dev)
         self.nocc = inp.nocc
         # flat device buffers: [dm | cocc] arrives in one upload, [J | K | Vxc] leaves in one download
         n2 = nao * nao

@@ -24,7 +24,9 @@ def _rank_main(rank, world, port, fn, eri_mode, out_dir, device_resident=False, 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        inp = inputs.build("H2O", "def2-svp", 3, verbose=False, eri_mode=eri_mode, chol_tol=1e-10)
+        # Cholesky vectors: factorised on rank 0 alone, slices sent to the ranks (inputs.build(world > 1))
+        inp = inputs.build("H2O", "def2-svp", 3, device="cuda:0" if eri_mode == "cholesky" else "cpu", verbose=False, eri_mode=eri_mode,
+                           chol_tol=1e-10, rank=rank, world=world)
         be = scf.HipBackend(inp, fn, rank=rank, world=world, device="cuda:0", device_resident=device_resident, eigensolver=eigensolver)
         res = scf.run_scf(inp, be, fn, log=None, conv_e=1e-11, conv_dm=1e-9)
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), e=res["E_tot"], exc=res["E_xc"], ex=res["E_ex_hf"],

@@ -165,3 +165,35 @@ def test_two_rank_gloo_row_sharded_dense_jk(tmp_path):
     assert np.array_equal(a, b)
     assert np.abs(a[: n * n].reshape(n, n) - J_ref).max() <= 1e-12 * np.abs(J_ref).max()
     assert np.abs(a[n * n:].reshape(n, n) - K_ref).max() <= 1e-12 * np.abs(K_ref).max()
+
+
+def _chol_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from quantum_compute_dft_amd import inputs
+        inp = inputs.build("H2O", "def2-svp", 1, verbose=False, eri_mode="cholesky", chol_tol=1e-10, rank=rank, world=world)
+        lo, hi, naux = inp.chol_range
+        assert inp.chol.shape == (hi - lo, inp.shells.nao, inp.shells.nao)
+        np.savez(os.path.join(out_dir, f"chol{rank}.npz"), L=np.asarray(inp.chol), lo=lo, hi=hi, naux=naux)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cholesky_vectors_are_factorised_once_and_scattered(tmp_path):
+    """inputs.build(world = 2): rank 0 alone factorises the ERI, each rank receives its vector slice
+    (grid_shard.scatter_vectors) -- the slices put together are the single-rank vectors to 1e-12 (the reference builds its
+    dense ERI once in its single process, grid.py:65; no rank here repeats the factorisation on 1/N of the cores)."""
+    from quantum_compute_dft_amd import inputs
+    from quantum_compute_dft_amd.grid_shard import vector_bounds
+    world = 2
+    mp.spawn(_chol_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = inputs.build("H2O", "def2-svp", 1, verbose=False, eri_mode="cholesky", chol_tol=1e-10)
+    parts = [np.load(tmp_path / f"chol{r}.npz") for r in range(world)]
+    naux = ref.chol.shape[0]
+    assert all(int(p["naux"]) == naux for p in parts)
+    for r, p in enumerate(parts):
+        assert (int(p["lo"]), int(p["hi"])) == vector_bounds(naux, world, r)
+    got = np.concatenate([p["L"] for p in parts])
+    assert got.shape == ref.chol.shape
+    assert np.abs(got - ref.chol).max() <= 1e-12
