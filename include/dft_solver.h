@@ -200,6 +200,23 @@ int DFT_ComputeXCDirect(XCSolver *solver, long long ngrid, int nao, int nshell,
                         unsigned long long d_exc_ptr,
                         long long chunk_points);
 
+/* Columns of the electron-repulsion matrix on the device: all (ij|kl) with k in shell C and l in shell D, for every
+ * i >= j -- what the integral-direct pivoted Cholesky factorisation of the ERI asks for per pivot (cholesky.py; the
+ * reference builds the whole tensor on the host with PySCF, `mol.intor('int2e')` at grid.py:65).  Device counterpart
+ * of the host engine's column routine (csrc/integrals.c::qc_eri_cols2: same McMurchie-Davidson formulation, s-f
+ * shells, same Schwarz screening).  Shell table as for DFT_EvalAO (host arrays, copied once); qmax_pairs: the Schwarz
+ * bounds sqrt(max (ab|ab)) of the nshell (nshell + 1) / 2 shell pairs a >= b in the order a (a + 1) / 2 + b.
+ * DFT_EriColumns clears and fills d_out: ((2 l_C + 1)(2 l_D + 1), nao, nao) f64, matrix (k, l) at index
+ * k (2 l_D + 1) + l, elements i >= j only (each matrix is symmetric; the other triangle stays zero).  Asynchronous on
+ * the handle's stream (default: the null stream).  Returns 0 or -1 (DFT_EriColumnsLastError). */
+void *DFT_EriColumnsOpen(int nshell, const double *shl_xyz, const int *shl_l, const int *shl_nprim,
+                         const int *shl_off, const int *shl_ao, const double *prim_exp, const double *prim_coef,
+                         int nao, int nprim_total, const double *qmax_pairs);
+int DFT_EriColumns(void *handle, int shell_C, int shell_D, double screen, unsigned long long d_out_ptr);
+int DFT_EriColumnsSetStream(void *handle, unsigned long long hip_stream);
+const char *DFT_EriColumnsLastError(void *handle);
+void DFT_EriColumnsClose(void *handle);
+
 /* Options: "quirks" (1 = reference formulas as shipped, default; 0 = corrected
  * VWN5 / PBE-c derivatives), "path" (0 = auto: wave-specialised
  * persistent MFMA kernels for nao <= 128, generic MFMA kernels above; 1 =

@@ -14,7 +14,7 @@ import numpy as np
 from .integrals import EriColumns
 
 
-def cholesky_eri(shells, tol=1e-8, span=0.01, max_vectors=None, screen=None, verbose=False, device=None):
+def cholesky_eri(shells, tol=1e-8, span=0.01, max_vectors=None, screen=None, verbose=False, device=None, device_columns=True):
     """Returns L of shape (naux, nao, nao), float64, every L[P] symmetric: a numpy array, or -- with `device` a
     CUDA/HIP torch device -- a tensor that stays on that device (the vectors are consumed there by
     DFT_ComputeJKFactorized; 9.5 GB at Anthracene/def2-TZVP never cross PCIe).
@@ -26,18 +26,26 @@ def cholesky_eri(shells, tol=1e-8, span=0.01, max_vectors=None, screen=None, ver
     from .hostinfo import blas_threads
     with blas_threads():
         if device is not None and str(device).startswith("cuda"):
-            return _cholesky_eri_device(shells, tol, span, max_vectors, screen, verbose, device)
+            return _cholesky_eri_device(shells, tol, span, max_vectors, screen, verbose, device, device_columns)
         return _cholesky_eri(shells, tol, span, max_vectors, screen, verbose)
 
 
-def _cholesky_eri_device(shells, tol, span, max_vectors, screen, verbose, device):
+def _cholesky_eri_device(shells, tol, span, max_vectors, screen, verbose, device, device_columns=True):
+    """`device_columns`: the pivots' integral columns come from the device kernel (csrc/eri_cols.hip) -- only the
+    diagonal (ij|ij) and its Schwarz bounds are still the host engine's; False = host columns through pinned memory
+    (round 2's path: 8.7 of the 11.5 s of an Anthracene/def2-TZVP factorisation)."""
     import torch
+    from .integrals import DeviceEriColumns, schwarz_bounds
     dev = torch.device(device)
     n = shells.nao
     n2 = n * n
     eri = EriColumns(shells)
+    dcols = None
     try:
-        diag = torch.as_tensor(eri.diag().reshape(n2).copy(), device=dev)
+        diag_h = eri.diag()
+        if device_columns:
+            dcols = DeviceEriColumns(shells, schwarz_bounds(shells, diag_h))
+        diag = torch.as_tensor(diag_h.reshape(n2).copy(), device=dev)
         shell_of = np.empty(n, dtype=np.int64)
         for s in range(shells.nshell):
             shell_of[shells.ao[s]:shells.ao[s] + 2 * shells.l[s] + 1] = s
@@ -45,8 +53,11 @@ def _cholesky_eri_device(shells, tol, span, max_vectors, screen, verbose, device
         cap = min(cap_max, 4 * n)
         L = torch.empty((cap, n2), dtype=torch.float64, device=dev)
         maxq = (2 * int(np.max(shells.l)) + 1) ** 2
-        stage = torch.empty((maxq, n2), dtype=torch.float64).pin_memory()    # the host engine writes the columns here
-        stage_np = stage.numpy()
+        if dcols is None:
+            stage = torch.empty((maxq, n2), dtype=torch.float64).pin_memory()    # the host engine writes the columns here
+            stage_np = stage.numpy()
+        else:
+            dstage = torch.empty((maxq, n2), dtype=torch.float64, device=dev)    # ... or the device kernel, here
         k = 0
         screen = tol * 1e-4 if screen is None else screen
         while k < cap_max:
@@ -60,8 +71,11 @@ def _cholesky_eri_device(shells, tol, span, max_vectors, screen, verbose, device
             nq = nc * nd
             qidx_h = ((c0 + np.arange(nc))[:, None] * n + (d0 + np.arange(nd))[None, :]).reshape(-1)
             qidx = torch.as_tensor(qidx_h, device=dev)
-            eri.cols(C, D, screen, out=stage_np[:nq], lower_only=True)     # the host writes i >= j only (integrals.c)
-            low = stage[:nq].to(dev, non_blocking=True).view(nq, n, n)
+            if dcols is None:
+                eri.cols(C, D, screen, out=stage_np[:nq], lower_only=True)     # the host writes i >= j only (integrals.c)
+                low = stage[:nq].to(dev, non_blocking=True).view(nq, n, n)
+            else:
+                low = dcols.cols(C, D, screen, dstage)                         # the same, computed in HBM
             res = (torch.tril(low) + torch.tril(low, -1).transpose(1, 2)).reshape(nq, n2)   # ... and the device mirrors
             if k:
                 res -= L[:k, qidx].T @ L[:k]
@@ -86,6 +100,8 @@ def _cholesky_eri_device(shells, tol, span, max_vectors, screen, verbose, device
         return L[:k].clone().reshape(k, n, n)
     finally:
         eri.close()
+        if dcols is not None:
+            dcols.close()
 
 
 def _cholesky_eri(shells, tol, span, max_vectors, screen, verbose):

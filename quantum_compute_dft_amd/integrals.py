@@ -155,3 +155,55 @@ class EriColumns:
         if rc != 0:
             raise RuntimeError("qc_eri_cols failed (diag() must be called first)")
         return out.reshape(nf, self.nao, self.nao)
+
+
+def schwarz_bounds(shells, diag):
+    """sqrt(max (ab|ab)) per shell pair a >= b, in the order a (a + 1) / 2 + b (what integrals.c keeps internally after
+    qc_eri_diag), from the (nao, nao) diagonal `diag` of the ERI matrix."""
+    ao0 = np.asarray(shells.ao, dtype=np.int64)
+    blk = np.maximum.reduceat(np.maximum.reduceat(np.asarray(diag), ao0, axis=0), ao0, axis=1)     # (nshell, nshell) block maxima
+    a, b = np.tril_indices(shells.nshell)                                                          # row-major: a (a + 1) / 2 + b
+    return np.sqrt(np.maximum(blk[a, b], 0.0))
+
+
+class DeviceEriColumns:
+    """The same columns computed ON THE DEVICE (libdft.so: csrc/eri_cols.hip, DFT_EriColumns) into a torch tensor: the
+    pivoted Cholesky factorisation keeps its algebra there, so the columns never cross PCIe.  `qmax`: schwarz_bounds()."""
+
+    def __init__(self, shells, qmax, lib_path=None):
+        from .build import library_path
+        from .solver import load_library
+        self.lib = load_library(lib_path or library_path())
+        L = self.lib
+        dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+        L.DFT_EriColumnsOpen.argtypes = [ctypes.c_int, dp, ip, ip, ip, ip, dp, dp, ctypes.c_int, ctypes.c_int, dp]
+        L.DFT_EriColumnsOpen.restype = ctypes.c_void_p
+        L.DFT_EriColumns.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_uint64]
+        L.DFT_EriColumns.restype = ctypes.c_int
+        L.DFT_EriColumnsLastError.argtypes = [ctypes.c_void_p]
+        L.DFT_EriColumnsLastError.restype = ctypes.c_char_p
+        L.DFT_EriColumnsClose.argtypes = [ctypes.c_void_p]
+        L.DFT_EriColumnsClose.restype = None
+        keep, p = _args(shells)
+        q = np.ascontiguousarray(qmax, dtype=np.float64)
+        assert q.shape == (shells.nshell * (shells.nshell + 1) // 2,)
+        self.shells, self.nao = shells, shells.nao
+        self._h = L.DFT_EriColumnsOpen(shells.nshell, *p, shells.nao, len(shells.exp), q.ctypes.data_as(dp))
+        if not self._h:
+            raise RuntimeError("DFT_EriColumnsOpen failed (no device, or angular momentum above f)")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.DFT_EriColumnsClose(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def cols(self, C, D, screen, out):
+        """Fills the torch tensor `out` ((2 l_C + 1)(2 l_D + 1) x nao x nao doubles on the device; elements i >= j only) and
+        returns it viewed as (nq, nao, nao).  Asynchronous on the null stream, like torch's own kernels."""
+        nq = (2 * int(self.shells.l[C]) + 1) * (2 * int(self.shells.l[D]) + 1)
+        assert out.is_cuda and out.is_contiguous() and out.numel() >= nq * self.nao * self.nao
+        if self.lib.DFT_EriColumns(self._h, int(C), int(D), float(screen), ctypes.c_uint64(out.data_ptr())) != 0:
+            raise RuntimeError("libdft: " + (self.lib.DFT_EriColumnsLastError(self._h) or b"").decode())
+        return out.view(-1)[:nq * self.nao * self.nao].view(nq, self.nao, self.nao)

@@ -1,0 +1,78 @@
+"""DFT_EriColumns (csrc/eri_cols.hip) -- the ERI columns of a ket shell pair on the device -- against the host engine
+(csrc/integrals.c::qc_eri_cols2, itself pinned by tests/test_integrals.py and test_integral_identities.py; the reference
+takes these integrals from libcint, grid.py:65).  Every angular-momentum class up to (ff|ff), swapped shell order,
+Schwarz screening, and the Cholesky factorisation built on it."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from quantum_compute_dft_amd import basis, cholesky, integrals  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _compare(sh, pairs, dev, screen=1e-14, tol=1e-12):
+    host = integrals.EriColumns(sh)
+    q = integrals.schwarz_bounds(sh, host.diag())
+    devc = integrals.DeviceEriColumns(sh, q)
+    n = sh.nao
+    worst = 0.0
+    for C, D in pairs:
+        ref = host.cols(C, D, screen, lower_only=True)
+        buf = torch.full((ref.shape[0] * n * n,), 7.0, dtype=torch.float64, device=dev)     # must be cleared by the call
+        got = devc.cols(C, D, screen, buf).cpu().numpy()
+        assert got.shape == ref.shape
+        err = np.abs(got - ref).max()
+        worst = max(worst, err)
+        assert err <= tol * max(1.0, np.abs(ref).max()), (C, D, err)
+    host.close(); devc.close()
+    return worst
+
+
+def test_every_class_up_to_ffff_on_a_ch_fragment(dev):
+    syms, xyz = ["C", "H"], np.array([[0.10, -0.20, 0.05], [1.25, 0.90, 1.60]])
+    sh = basis.build_shells(syms, xyz, "def2-tzvp")                     # C: 5s 3p 2d 1f, H: 3s 1p
+    by_l = {l: [i for i, x in enumerate(sh.l) if x == l] for l in range(4)}
+    pairs = []
+    for lc in range(4):
+        for ld in range(4):
+            C, D = by_l[lc][0], by_l[ld][-1]
+            pairs.append((C, D))
+            if C != D:
+                pairs.append((D, C))                                    # the swapped order of the same pair
+    worst = _compare(sh, pairs, dev)
+    assert worst < 1e-12
+
+
+def test_benzene_def2svp_blocks_and_screening(dev):
+    import os
+    from quantum_compute_dft_amd import inputs
+    syms, xyz = basis.parse_xyz(os.path.join(inputs.DATA_DIR, "Benzene.xyz"))
+    sh = basis.build_shells(syms, xyz, "def2-svp")
+    rng = np.random.default_rng(5)
+    pairs = [(int(a), int(b)) for a, b in rng.integers(0, sh.nshell, size=(8, 2))]
+    d = [i for i, l in enumerate(sh.l) if l == 2]
+    pairs += [(d[0], d[-1]), (d[3], 0)]
+    _compare(sh, pairs, dev, screen=1e-14)
+    _compare(sh, pairs[:4], dev, screen=1e-6, tol=1e-12)              # the same quartets are skipped on both sides
+
+
+def test_cholesky_with_device_columns_matches_host_columns(dev):
+    syms, xyz = basis.parse_xyz("O 0 0 0.1173; H 0 0.7572 -0.4692; H 0 -0.7572 -0.4692")
+    sh = basis.build_shells(syms, np.asarray(xyz), "def2-svp")
+    La = cholesky.cholesky_eri(sh, tol=1e-10, device=dev, device_columns=True)
+    Lb = cholesky.cholesky_eri(sh, tol=1e-10, device=dev, device_columns=False)
+    # (the vectors themselves may differ: near-degenerate pivots are taken in another order when the columns differ in
+    # the last bits; what the factorisation promises is the residual bound)
+    assert abs(La.shape[0] - Lb.shape[0]) <= 2
+    eri = integrals.int2e(sh)
+    for L in (La, Lb):
+        approx = torch.einsum("pij,pkl->ijkl", L, L).cpu().numpy()
+        assert np.abs(approx - eri).max() <= 1e-9
+        assert float((L - L.transpose(1, 2)).abs().max()) == 0.0 or float((L - L.transpose(1, 2)).abs().max()) < 1e-14
