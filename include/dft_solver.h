@@ -153,9 +153,9 @@ int DFT_ComputeJKRows(XCSolver *solver, int nao, int i_lo, int i_hi,
  * d_cocc_ptr: (nao, nocc) f64 C-order with dm = cocc . cocc^T (occupation folded in,
  * i.e. sqrt(2) C_occ for the closed-shell dm of dft.py:181-182).  d_J_ptr or d_K_ptr
  * may be 0; J needs d_dm_ptr, K needs d_cocc_ptr.  When BOTH are requested the contraction
- * L_P : dm that J needs is taken from the half-transformed vectors and cocc (it rides in
- * the K build), i.e. dm = cocc . cocc^T is relied upon; for a J of a density that is not
- * cocc . cocc^T call once for J alone (d_K_ptr = 0), which contracts dm itself.
+ * L_P : dm that J needs rides in the K build (taken from the half-transformed vectors and
+ * cocc) as long as dm IS cocc . cocc^T -- checked on the device in every call; for any other
+ * dm (damped, mixed, fractional occupations) J contracts dm itself in a pass of its own.
  * Asynchronous; returns 0 or -1 (DFT_GetLastError). */
 int DFT_ComputeJKFactorized(XCSolver *solver, int nao, int naux, int nocc,
                             unsigned long long d_chol_ptr,

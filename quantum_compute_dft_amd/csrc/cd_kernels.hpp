@@ -261,15 +261,54 @@ __global__ __launch_bounds__(256) void k_mirror_lower(int n, double *__restrict_
     if ((a / 128) * 128 >= (b / CD_BN) * CD_BN + CD_BN) K[e] = K[(size_t)b * n + a];
 }
 
-// v[P] = sum_b vpart[P][b]: the per-b-block partials the half transform leaves (DOT), fixed order
+// v[P] = sum_b vpart[P][b]: the per-b-block partials the half transform leaves (DOT), fixed order -- unless the
+// caller's dm turned out NOT to be cocc cocc^T (flag set by k_dm_consistency): then v[P] = L_P : dm as k_cd_dot
+// computed it from dm itself.
 __global__ __launch_bounds__(256) void k_cd_vsum(int naux, int nB, const double *__restrict__ vpart,
-                                                 double *__restrict__ v)
+                                                 double *__restrict__ v, const int *__restrict__ flag = nullptr,
+                                                 const double *__restrict__ vdot = nullptr)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= naux) return;
+    if (flag && *flag) {
+        v[p] = vdot[p];
+        return;
+    }
     double s = 0.0;
     for (int b = 0; b < nB; ++b) s += vpart[(size_t)p * nB + b];
     v[p] = s;
+}
+
+// flag = 1 when dm differs from cocc cocc^T beyond round-off somewhere (a damped or mixed density, fractional
+// occupations, orbitals passed without the sqrt(2)): J must then contract dm itself.  The host clears `flag`.
+__global__ __launch_bounds__(256) void k_dm_consistency(int nao, int nocc, const double *__restrict__ dm,
+                                                        const double *__restrict__ c, int *__restrict__ flag)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)nao * nao) return;
+    const int a = (int)(e / nao), b = (int)(e % nao);
+    const double *ca = c + (size_t)a * nocc, *cb = c + (size_t)b * nocc;
+    double s = 0.0, m = 0.0;
+    for (int i = 0; i < nocc; ++i) { s += ca[i] * cb[i]; m += fabs(ca[i] * cb[i]); }
+    if (fabs(dm[e] - s) > 1e-11 * (m + fabs(dm[e])) + 1e-14) atomicOr(flag, 1);
+}
+
+// k_cd_dot that only works when the flag is set (a launch that exits at once otherwise)
+__global__ __launch_bounds__(256) void k_cd_dot_if(const int *__restrict__ flag, long n2, const double *__restrict__ L,
+                                                   const double *__restrict__ D, double *__restrict__ v)
+{
+    if (!*flag) return;
+    __shared__ double red[256];
+    const double *Lp = L + (size_t)blockIdx.x * n2;
+    double s = 0.0;
+    for (long e = threadIdx.x; e < n2; e += 256) s += Lp[e] * D[e];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) v[blockIdx.x] = red[0];
 }
 
 // part[y][e] = sum_{P in slice y} v[P] L[P][e]; slices of `pslice` vectors, summed afterwards

@@ -487,7 +487,7 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
     // (D = Cocc Cocc^T is the entry point's contract), one partial per tile; otherwise a pass of its own over L with D.
     const bool fused_dot = J && K;
     if (J) {
-        if (!reserve(s, s->cdv, sizeof(double) * (size_t)naux * (1 + npair_h), "hipMalloc(cd v)")) return -1;
+        if (!reserve(s, s->cdv, sizeof(double) * ((size_t)naux * (2 + npair_h) + 2), "hipMalloc(cd v)")) return -1;
         if (!fused_dot) {
             ScopedTimer t(s, "cd_dot");
             hipLaunchKernelGGL(k_cd_dot, dim3((unsigned)naux), dim3(256), 0, st, n2, L, dm, (double *)s->cdv.p);
@@ -558,7 +558,17 @@ int jk_factorized(XCSolver *s, int nao, int naux, int nocc, const double *L, con
         nsl = (naux + pslice - 1) / pslice;
         if (!reserve(s, s->jpart, sizeof(double) * (size_t)nsl * n2, "hipMalloc(cd J slabs)")) return -1;
         double *jp = (double *)s->jpart.p;
-        if (fused_dot) hipLaunchKernelGGL(k_cd_vsum, dim3((unsigned)((naux + 255) / 256)), dim3(256), 0, st, naux, npair_h, vpart, v);
+        if (fused_dot) {
+            // The fused dots are L_P : (cocc cocc^T).  A dm that is NOT that product (damped, mixed, fractional occupations)
+            // must give ITS Coulomb matrix: checked on the device, and v_P = L_P : dm is then taken in a pass of its own
+            // (a launch that exits at once when the two agree) -- no host round trip either way.
+            double *vdot = vpart + (size_t)naux * npair_h;
+            int *flag = (int *)(vdot + naux);
+            (void)hipMemsetAsync(flag, 0, sizeof(int), st);
+            hipLaunchKernelGGL(k_dm_consistency, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, nao, nocc, dm, cocc, flag);
+            hipLaunchKernelGGL(k_cd_dot_if, dim3((unsigned)naux), dim3(256), 0, st, flag, n2, L, dm, vdot);
+            hipLaunchKernelGGL(k_cd_vsum, dim3((unsigned)((naux + 255) / 256)), dim3(256), 0, st, naux, npair_h, vpart, v, flag, vdot);
+        }
         hipLaunchKernelGGL(k_cd_axpy, dim3((unsigned)eb, (unsigned)nsl), dim3(256), 0, st, n2, naux, pslice, L, v, jp, nao);
         hipLaunchKernelGGL(k_sum_slabs8, dim3((unsigned)((n2 + 31) / 32)), dim3(256), 0, st, (size_t)n2, nsl, (size_t)n2, jp, J);
         hipLaunchKernelGGL(k_sym_from_upper, dim3((unsigned)eb), dim3(256), 0, st, nao, J);

@@ -561,6 +561,33 @@ def test_factorised_jk_matches_numpy_restatement(dev, nao, naux, nocc):
         w.compute_jk_factorized(nao, naux, 0, d_L, d_dm, None, None, d_K2)   # K without orbitals
 
 
+@pytest.mark.parametrize("nao,naux,nocc", [(114, 300, 21), (150, 33, 70), (37, 50, 16)])
+def test_factorised_j_of_a_density_that_is_not_cocc_cocc_t(dev, nao, naux, nocc):
+    """J and K requested together take L_P : dm from the half-transformed vectors, which presumes dm = cocc cocc^T.  A dm
+    that is NOT that product -- a damped / mixed density, here 0.7 dm + 0.3 dm' -- must still give ITS Coulomb matrix
+    (the reference's J is a contraction with whatever dm it is handed, dft_solver.cu:550-555): the library checks the
+    product on the device and contracts dm itself when it fails.  K follows the orbitals, as documented."""
+    chol, cocc, dm = _factor_case(nao, naux, nocc, 300 + nao)
+    _, cocc2, dm2 = _factor_case(nao, naux, nocc, 900 + nao)
+    mixed = 0.7 * dm + 0.3 * dm2
+    J_ref, _ = oracle.jk_from_factors(chol, mixed)
+    _, K_ref = oracle.jk_from_factors(chol, cocc @ cocc.T)
+    w = _solver(2)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    d_L, d_dm, d_c = t(chol), t(mixed), t(cocc)
+    d_J = torch.full((nao, nao), 7.0, dtype=torch.float64, device=dev); d_K = torch.full_like(d_J, 7.0)
+    assert w.compute_jk_factorized(nao, naux, nocc, d_L, d_dm, d_c, d_J, d_K) == 0
+    torch.cuda.synchronize()
+    assert np.abs(d_J.cpu().numpy() - J_ref).max() <= 1e-12 * np.abs(J_ref).max()
+    assert np.abs(d_K.cpu().numpy() - K_ref).max() <= 1e-12 * np.abs(K_ref).max()
+    # and a consistent dm right after it on the same solver takes the fused dots again (same J as a J-only call to round-off)
+    d_dm.copy_(t(dm))
+    assert w.compute_jk_factorized(nao, naux, nocc, d_L, d_dm, d_c, d_J, d_K) == 0
+    J_ref2, _ = oracle.jk_from_factors(chol, dm)
+    torch.cuda.synchronize()
+    assert np.abs(d_J.cpu().numpy() - J_ref2).max() <= 1e-12 * np.abs(J_ref2).max()
+
+
 @pytest.mark.parametrize("bname,tol", [("sto-3g", 1e-10), ("def2-svp", 1e-9)])
 def test_factorised_jk_matches_dense_eri_oracle(dev, bname, tol):
     """Cholesky vectors of the real H2O ERI: J, K agree with the reference's dense contractions
