@@ -398,7 +398,7 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
             hipLaunchKernelGGL(k_reduce_slabs8<false>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
         }
         // last launch of the call: Exc to the device scalar and to host-mapped memory
-        hipLaunchKernelGGL(k_finish_exc, dim3(1), dim3(256), 0, st, nxb, partial, exc, want_host_exc ? s->h_exc_dev : nullptr);
+        hipLaunchKernelGGL(k_finish_exc, dim3(1), dim3(64), 0, st, nxb, partial, exc, want_host_exc ? s->h_exc_dev : nullptr);
     }
     return hip_ok(s, hipGetLastError(), "XC sweep launch");
 }

@@ -499,22 +499,18 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
 // of the call, so the host may return as soon as it sees the value (no copy launch, no sleeping
 // synchronise).  (A last-block ticket with a fence inside the reduce kernel was tried first: its per-block
 // __threadfence() cost 10-30 us.)
-__global__ __launch_bounds__(256) void k_finish_exc(long npart, const double *__restrict__ partial,
-                                                    double *__restrict__ exc_dev, double *exc_host)
+__global__ __launch_bounds__(64) void k_finish_exc(long npart, const double *__restrict__ partial,
+                                                   double *__restrict__ exc_dev, double *exc_host)
 {
-    __shared__ double part[256];
+    // ONE wave: strided partial sums, then a fixed shuffle tree -- no LDS, no barrier (the launch is on the critical path
+    // of every synchronous call: 4.0 us as a 256-thread block with an LDS tree, rocprofv3)
     double x = 0.0;
-    for (long i = threadIdx.x; i < npart; i += 256) x += partial[i];
-    part[threadIdx.x] = x;
-    __syncthreads();
-    for (int m = 128; m >= 1; m >>= 1) {
-        if ((int)threadIdx.x < m) part[threadIdx.x] += part[threadIdx.x + m];
-        __syncthreads();
-    }
+    for (long i = threadIdx.x; i < npart; i += 64) x += partial[i];
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_down(x, m, 64);
     if (threadIdx.x == 0) {
-        exc_dev[0] = part[0];
+        exc_dev[0] = x;
         if (exc_host) {
-            *(volatile double *)exc_host = part[0];
+            *(volatile double *)exc_host = x;
             __threadfence_system();
         }
     }
