@@ -395,10 +395,15 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
                                want_host_exc ? s->h_exc_dev : nullptr);
             return hip_ok(s, hipGetLastError(), "XC sweep launch");
         } else {
-            hipLaunchKernelGGL(k_reduce_slabs8<false>, g, dim3(256), 0, st, nao, nslab, slabs, vxc);
+            // Exc is summed by the reduce kernel's highest-index block into the DEVICE scalar only; publishing it to the host
+            // is left to a one-thread kernel behind it (stream order: the whole call has completed when the word appears) --
+            // the shortest launch there is, instead of a finishing kernel that still has the partials to add up
+            hipLaunchKernelGGL((k_reduce_slabs8<false, true>), g, dim3(256), 0, st, nao, nslab, slabs, vxc, nxb, partial, exc, (double *)nullptr);
+            if (want_host_exc && s->h_exc_dev) hipLaunchKernelGGL(k_publish_exc, dim3(1), dim3(1), 0, st, exc, s->h_exc_dev);
+            return hip_ok(s, hipGetLastError(), "XC sweep launch");
         }
         // last launch of the call: Exc to the device scalar and to host-mapped memory
-        hipLaunchKernelGGL(k_finish_exc, dim3(1), dim3(64), 0, st, nxb, partial, exc, want_host_exc ? s->h_exc_dev : nullptr);
+        hipLaunchKernelGGL(k_finish_exc, dim3(1), dim3(256), 0, st, nxb, partial, exc, want_host_exc ? s->h_exc_dev : nullptr);
     }
     return hip_ok(s, hipGetLastError(), "XC sweep launch");
 }

@@ -499,21 +499,34 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_rho_ws(long ngrid, int nao,
 // of the call, so the host may return as soon as it sees the value (no copy launch, no sleeping
 // synchronise).  (A last-block ticket with a fence inside the reduce kernel was tried first: its per-block
 // __threadfence() cost 10-30 us.)
-__global__ __launch_bounds__(64) void k_finish_exc(long npart, const double *__restrict__ partial,
-                                                   double *__restrict__ exc_dev, double *exc_host)
+__global__ __launch_bounds__(256) void k_finish_exc(long npart, const double *__restrict__ partial,
+                                                    double *__restrict__ exc_dev, double *exc_host)
 {
-    // ONE wave: strided partial sums, then a fixed shuffle tree -- no LDS, no barrier (the launch is on the critical path
-    // of every synchronous call: 4.0 us as a 256-thread block with an LDS tree, rocprofv3)
+    // strided partial sums (every thread's loads in flight together), a shuffle tree per wave, four wave sums through LDS:
+    // one barrier.  (The launch is on the critical path of every synchronous call: an eight-barrier LDS tree took 4.0 us,
+    // a single wave walking the partials one after another 5.8 us, rocprofv3.)
+    __shared__ double part[4];
     double x = 0.0;
-    for (long i = threadIdx.x; i < npart; i += 64) x += partial[i];
+    for (long i = threadIdx.x; i < npart; i += 256) x += partial[i];
     for (int m = 32; m >= 1; m >>= 1) x += __shfl_down(x, m, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = x;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        exc_dev[0] = x;
+        const double e = (part[0] + part[1]) + (part[2] + part[3]);
+        exc_dev[0] = e;
         if (exc_host) {
-            *(volatile double *)exc_host = x;
+            *(volatile double *)exc_host = e;
             __threadfence_system();
         }
     }
+}
+
+// The call's last launch on the default path: the device scalar (complete: an earlier kernel of the stream wrote it) goes to
+// the host-mapped word.  Seeing it, the host knows every kernel of the call has completed.
+__global__ void k_publish_exc(const double *__restrict__ exc_dev, double *exc_host)
+{
+    *(volatile double *)exc_host = exc_dev[0];
+    __threadfence_system();
 }
 
 // V = sum of the per-workgroup slabs in a fixed order (bitwise reproducible): 32 elements x 8

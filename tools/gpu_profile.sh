@@ -4,7 +4,7 @@
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 timeout -k 10 600 python -m pytest tests -q -m gpu -x > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/${TAG}_pytest_gpu.log
 timeout -k 10 400 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"
 rm -rf $OUT/prof_$TAG; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 bench.py --no-cpu-baseline --no-extra-legs --no-k-build > $OUT/${TAG}_bench_prof.json 2> $OUT/${TAG}_prof.err; echo "rocprof rc=$?"
