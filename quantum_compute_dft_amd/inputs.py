@@ -81,7 +81,7 @@ def build(atom_path, basis_name="sto-3g", grid_level=3, device="cpu", verbose=Tr
         else:
             chol = cholesky_eri(shells, tol=chol_tol, device=device)   # on a GPU: the factorisation's algebra and the vectors stay there
         if verbose:
-            where = "integral columns on the host, algebra and vectors on the device" if str(device).startswith("cuda") else "on the host"
+            where = "integral columns (DFT_EriColumns), algebra and vectors on the device" if str(device).startswith("cuda") else "on the host"
             print(f"Cholesky vectors of the ERI: {chol.shape[0]} (threshold {chol_tol:g}, {time.time() - t0:.1f} s; {where})")
     else:
         raise ValueError(f"eri_mode {eri_mode!r}: expected 'dense' or 'cholesky'")

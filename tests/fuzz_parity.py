@@ -1,4 +1,4 @@
-"""Randomised parity sweep on the GPU: DFT_ComputeXC (all functionals, all kernel paths), dense and factorised
+"""Randomised parity sweep on the GPU: DFT_ComputeXC / DFT_ComputeXCOcc (all functionals, all kernel paths), dense and factorised
 J/K, AO evaluation -- each against the oracle on random sizes.  usage: python tests/fuzz_parity.py [seconds] [seed]  (a checker like the tests next to it: the only places the oracle is used from)"""
 import sys, time, numpy as np, torch
 import os; _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'tests'))
@@ -13,7 +13,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
 t_end = time.time() + budget
-n_xc = n_jk = n_cd = n_ao = n_direct = 0
+n_xc = n_jk = n_cd = n_ao = n_direct = n_occ = 0
 worst = {"xc_e": 0.0, "xc_v": 0.0, "jk": 0.0, "cd": 0.0, "ao": 0.0}
 names = ["LDA", "GGA", "B3LYP"]
 while time.time() < t_end:
@@ -24,6 +24,11 @@ while time.time() < t_end:
         if nao * ngrid > 1.2e6: ngrid = max(1, int(1.2e6 // nao))
         path = int(rng.choice([0, 0, 0, 1, 2])); quirks = int(rng.integers(0, 2))
         dm, ao, gr, w = synth_inputs(ngrid, nao, seed=int(rng.integers(1 << 30)))
+        occ_call = path == 0 and rng.random() < 0.5      # DFT_ComputeXCOcc: the same sweep through the occupied orbitals
+        if occ_call:
+            nocc = int(min(nao, rng.choice([1, 2, 5, 15, 16, 17, 21, 33, 47, 64, 65, 100, 129])))
+            cocc = np.sqrt(2.0) * 0.7 * np.random.default_rng(int(rng.integers(1 << 30))).standard_normal((nao, nocc))
+            dm = cocc @ cocc.T
         if rng.random() < 0.3: w[rng.integers(0, ngrid, size=max(1, ngrid // 7))] = 0.0
         e_ref, v_ref = oracle.compute_xc(xc, dm, ao, w, gr if xc else None, quirks=bool(quirks))
         s = q.DFTSolverWrapper(q.library_path(), names[xc]); s.set_option("path", path); s.set_option("quirks", quirks)
@@ -31,7 +36,12 @@ while time.time() < t_end:
         if rng.random() < 0.3: s.set_option("ws_waves", 16)
         s.set_option("sweep_order", int(rng.integers(0, 4)))
         d_v = torch.full((nao, nao), 3.0, dtype=torch.float64, device=dev)
-        e = s.compute_xc(ngrid, nao, t(dm), t(ao), t(w), d_v, t(gr) if xc else None)
+        if occ_call:
+            s.set_option("occ", int(rng.choice([0, 1, 1])))
+            e = s.compute_xc_occ(ngrid, nao, nocc, t(cocc), t(ao), t(w), d_v, t(gr) if xc else None, t(dm) if rng.random() < 0.5 else None)
+            n_occ += 1
+        else:
+            e = s.compute_xc(ngrid, nao, t(dm), t(ao), t(w), d_v, t(gr) if xc else None)
         ee = abs(e - e_ref) / max(1e-300, abs(e_ref)) if e_ref else abs(e)
         ve = np.abs(d_v.cpu().numpy() - v_ref).max() / max(1e-300, np.abs(v_ref).max())
         worst["xc_e"] = max(worst["xc_e"], ee); worst["xc_v"] = max(worst["xc_v"], ve); n_xc += 1
@@ -104,4 +114,4 @@ while time.time() < t_end:
             vd = float((d_v2 - d_v).abs().max()) / max(1e-300, float(d_v.abs().max()))
             worst["direct"] = max(worst.get("direct", 0.0), ed, vd); n_direct += 1
             assert ed < 1e-11 and vd < 1e-10, ("direct", bname, natm, ngrid, xc, ed, vd)
-print(f"fuzz ok: {n_xc} XC sweeps, {n_jk} dense J/K, {n_cd} factorised J/K, {n_ao} AO evaluations, {n_direct} direct sweeps; worst relative errors {worst}")
+print(f"fuzz ok: {n_xc} XC sweeps ({n_occ} of them through DFT_ComputeXCOcc), {n_jk} dense J/K, {n_cd} factorised J/K, {n_ao} AO evaluations, {n_direct} direct sweeps; worst relative errors {worst}")

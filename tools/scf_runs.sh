@@ -2,7 +2,7 @@
 # The driver end to end on the BASELINE molecules (real shells, real level-3 grids): logs for profiles/.
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out; mkdir -p $OUT; TAG=${TAG:-r02}
+OUT=gpurun_out; mkdir -p $OUT; TAG=${TAG:-r03}
 rm -f $OUT/${TAG}_scf.jsonl
 run() { name=$1; shift; echo "=== $name"; timeout -k 10 ${TO:-300} "$@" > $OUT/${TAG}_scf_$name.log 2>&1; echo "rc=$?"; grep -E "Total Energy|Converged|Median per cycle|Host part|Cholesky vectors|Unconverged|Error|Traceback" $OUT/${TAG}_scf_$name.log | head -8; }
 D="python -m quantum_compute_dft_amd.dft"
