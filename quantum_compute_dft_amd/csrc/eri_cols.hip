@@ -93,11 +93,16 @@ __device__ void hermite_E(int la, int lb, double a, double b, double XAB, double
     }
 }
 
-// LDS layout (doubles unless said otherwise), sizes by the launch's class:
-//   Ra, Rb   : RD^3 each (RD = L + 1)            wb : nab_c * MT   wk : ncd_c * MT
-//   Eab, Ecd : 3 * 112 each      F : 16      lists ob, ok (unsigned short): nab_c * MT, ncd_c * MT     nb, nk (int)
-// and the Cartesian block (nab_c * ncd_c doubles) aliases the front of it after the primitive loops.
-template <int NACC>
+// LDS layout (doubles unless said otherwise), sizes by the launch's class.  A workgroup works as 256 / TEAM teams of
+// TEAM threads: every team takes its own bra primitive pairs (round-robin) and has its own
+//   Ra, Rb : RD^3 each (RD = L + 1)      wb : nab_c * MT      Eab : 3 * 112      F : 16
+// while the ket side is shared:  wk : ncd_c * MT,  Ecd : 3 * 112,  lists ob, ok (unsigned short), counts nb, nk (int).
+// TEAM = 256: one team, every step between workgroup barriers (the classes with d or f functions on the bra: many
+// Cartesian components, one primitive pair).  TEAM = 64 (s and p on the bra: few components, up to 36 primitive pairs
+// per shell pair, and (ss|ss)-like quartets walk up to 36 x 36 primitive quartets): four waves, each on its own primitive
+// pairs with nothing but wave-level ordering between its steps; their accumulators are added in a fixed order at the end.
+// The Cartesian block (nab_c * ncd_c doubles per team) aliases the front of the allocation after the primitive loops.
+template <int NACC, int TEAM>
 __global__ __launch_bounds__(EC_T) void k_eri_cols(int nao, const double *__restrict__ xyz, const int *__restrict__ ls,
                                                    const int *__restrict__ nprim, const int *__restrict__ off,
                                                    const int *__restrict__ ao0, const double *__restrict__ ex,
@@ -107,7 +112,13 @@ __global__ __launch_bounds__(EC_T) void k_eri_cols(int nao, const double *__rest
                                                    double screen, int mt, double *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x;
+    constexpr int NTEAM = EC_T / TEAM;
+    const int tid = threadIdx.x, tl = tid % TEAM;
+    const int team = __builtin_amdgcn_readfirstlane(tid / TEAM);
+    auto team_sync = [&]() {
+        if (TEAM == EC_T) __syncthreads();
+        else __builtin_amdgcn_wave_barrier(); // one wave: its LDS operations complete in program order
+    };
     const int kab = pairs[blockIdx.x];
     if (qmax[kab] * qmax[kcd] < screen) return; // Schwarz: the block stays zero (the caller cleared `out`)
     const int A = pA[kab], B = pB[kab];
@@ -116,9 +127,10 @@ __global__ __launch_bounds__(EC_T) void k_eri_cols(int nao, const double *__rest
     const int nab = nca * ncb, ncdc = ncc * ncd, nout = nab * ncdc;
     const int Lab = la + lb, Lcd = lc + ld, L = Lab + Lcd, RD = L + 1, RD3 = RD * RD * RD;
 
-    double *Ra = lds, *Rb = Ra + RD3, *wb = Rb + RD3, *wk = wb + nab * mt, *Eab = wk + ncdc * mt, *Ecd = Eab + 3 * EC_ED,
-           *F = Ecd + 3 * EC_ED;
-    unsigned short *ob = reinterpret_cast<unsigned short *>(F + 16), *ok = ob + nab * mt;
+    const int TP = 2 * RD3 + nab * mt + 3 * EC_ED + 16; // doubles per team
+    double *Ra = lds + (size_t)team * TP, *Rb = Ra + RD3, *wb = Rb + RD3, *Eab = wb + nab * mt, *F = Eab + 3 * EC_ED;
+    double *wk = lds + (size_t)NTEAM * TP, *Ecd = wk + ncdc * mt;
+    unsigned short *ob = reinterpret_cast<unsigned short *>(Ecd + 3 * EC_ED), *ok = ob + nab * mt;
     int *nb = reinterpret_cast<int *>(ok + ncdc * mt + ((nab * mt + ncdc * mt) & 1)), *nk = nb + nab;
 
     // sparse Hermite lists of every component pair: offsets o = (t RD + u) RD + v, t <= ax+bx, u <= ay+by, v <= az+bz
@@ -147,6 +159,7 @@ __global__ __launch_bounds__(EC_T) void k_eri_cols(int nao, const double *__rest
     const double Rab2 = (RA[0] - RB[0]) * (RA[0] - RB[0]) + (RA[1] - RB[1]) * (RA[1] - RB[1]) + (RA[2] - RB[2]) * (RA[2] - RB[2]);
     const double Rcd2 = (RC[0] - RDc[0]) * (RC[0] - RDc[0]) + (RC[1] - RDc[1]) * (RC[1] - RDc[1]) + (RC[2] - RDc[2]) * (RC[2] - RDc[2]);
     const double two_pi_52 = 34.986836655249725; // 2 pi^(5/2)
+    const int npa = nprim[A], npb = nprim[B];
 
     for (int pc = 0; pc < nprim[C]; ++pc)
         for (int pd = 0; pd < nprim[D]; ++pd) {
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(EC_T) void k_eri_cols(int nao, const double *__rest
             if (fabs(ccd) * exp(-ec * ed / (ec + ed) * Rcd2) < 1e-18) continue; // the host drops these primitive pairs too (uniform)
             const double q = ec + ed;
             const double Q[3] = {(ec * RC[0] + ed * RDc[0]) / q, (ec * RC[1] + ed * RDc[1]) / q, (ec * RC[2] + ed * RDc[2]) / q};
-            __syncthreads(); // everyone is done with the previous wk / Ecd
+            __syncthreads(); // every team is done with the previous wk / Ecd
             if (tid < 3) hermite_E(lc, ld, ec, ed, RC[tid] - RDc[tid], Ecd + tid * EC_ED);
             __syncthreads();
             for (int k = tid; k < ncdc; k += EC_T) {
@@ -172,96 +185,108 @@ __global__ __launch_bounds__(EC_T) void k_eri_cols(int nao, const double *__rest
                     }
                 }
             }
-            for (int pa = 0; pa < nprim[A]; ++pa)
-                for (int pb = 0; pb < nprim[B]; ++pb) {
-                    const double ea = ex[off[A] + pa], eb = ex[off[B] + pb], cab = cf[off[A] + pa] * cf[off[B] + pb];
-                    if (fabs(cab) * exp(-ea * eb / (ea + eb) * Rab2) < 1e-18) continue;
-                    const double p = ea + eb;
-                    const double P[3] = {(ea * RA[0] + eb * RB[0]) / p, (ea * RA[1] + eb * RB[1]) / p, (ea * RA[2] + eb * RB[2]) / p};
-                    const double alpha = p * q / (p + q);
-                    const double PQ[3] = {P[0] - Q[0], P[1] - Q[1], P[2] - Q[2]};
-                    const double pref = two_pi_52 / (p * q * sqrt(p + q)) * cab * ccd;
-                    __syncthreads(); // previous quartet's contraction is over: wb, Eab, R tables are free
-                    if (tid < 3) hermite_E(la, lb, ea, eb, RA[tid] - RB[tid], Eab + tid * EC_ED);
-                    if (tid == 64) { // another wave, alongside: F_n scaled to R^n_000 = (-2 alpha)^n F_n (the host's order of operations)
-                        boys(L, alpha * (PQ[0] * PQ[0] + PQ[1] * PQ[1] + PQ[2] * PQ[2]), F);
-                        double f = 1.0;
-                        for (int n = 0; n <= L; ++n) { F[n] *= f; f *= -2.0 * alpha; }
-                    }
-                    __syncthreads();
-                    for (int k = tid; k < nab; k += EC_T) {
-                        const int ia = k / ncb, ib = k - ia * ncb;
-                        const int x1 = c_cx[la][ia], x2 = c_cx[lb][ib], y1 = c_cy[la][ia], y2 = c_cy[lb][ib], z1 = c_cz[la][ia], z2 = c_cz[lb][ib];
-                        int n = 0;
-                        for (int t = 0; t <= x1 + x2; ++t) {
-                            const double e1 = pref * Eab[0 * EC_ED + (x1 * 4 + x2) * 7 + t];
-                            for (int u = 0; u <= y1 + y2; ++u) {
-                                const double e2 = e1 * Eab[1 * EC_ED + (y1 * 4 + y2) * 7 + u];
-                                for (int v = 0; v <= z1 + z2; ++v) wb[k * mt + n++] = e2 * Eab[2 * EC_ED + (z1 * 4 + z2) * 7 + v];
-                            }
-                        }
-                    }
-                    // R^n_tuv, n = L .. 0 (integrals.c::hermite_R rearranged by auxiliary level): level n holds the orders
-                    // t+u+v <= L-n and needs level n+1 only
-                    double *cur = Ra, *nxt = Rb;
-                    {
-                        if (tid == 0) cur[0] = F[L];
-                        for (int n = L - 1; n >= 0; --n) {
-                            __syncthreads();
-                            const int smax = L - n, side = smax + 1;
-                            for (int e = tid; e < side * side * side; e += EC_T) {
-                                const int t = e / (side * side), u = (e / side) % side, v = e % side;
-                                const int s = t + u + v;
-                                if (s > smax) continue;
-                                double val;
-                                if (s == 0) {
-                                    val = F[n];
-                                } else if (t > 0) {
-                                    val = PQ[0] * cur[((t - 1) * RD + u) * RD + v];
-                                    if (t > 1) val += (t - 1) * cur[((t - 2) * RD + u) * RD + v];
-                                } else if (u > 0) {
-                                    val = PQ[1] * cur[(t * RD + u - 1) * RD + v];
-                                    if (u > 1) val += (u - 1) * cur[(t * RD + u - 2) * RD + v];
-                                } else {
-                                    val = PQ[2] * cur[(t * RD + u) * RD + v - 1];
-                                    if (v > 1) val += (v - 1) * cur[(t * RD + u) * RD + v - 2];
-                                }
-                                nxt[(t * RD + u) * RD + v] = val;
-                            }
-                            double *sw = cur; cur = nxt; nxt = sw;
-                        }
-                    }
-                    __syncthreads(); // `cur` = R^0, wb complete
-#pragma unroll
-                    for (int o = 0; o < NACC; ++o) {
-                        const int e = tid + o * EC_T;
-                        if (e < nout) {
-                            const int kb = e / ncdc, kc = e - kb * ncdc;
-                            const int n1 = nb[kb], n2 = nk[kc];
-                            const double *w1 = wb + kb * mt, *w2 = wk + kc * mt;
-                            const unsigned short *o1 = ob + kb * mt, *o2 = ok + kc * mt;
-                            double s = 0.0;
-                            for (int i = 0; i < n1; ++i) {
-                                const double *Rm = cur + o1[i];
-                                double g = 0.0;
-                                for (int j = 0; j < n2; ++j) g += w2[j] * Rm[o2[j]];
-                                s += w1[i] * g;
-                            }
-                            acc[o] += s;
+            __syncthreads(); // wk complete for every team
+            for (int pab = team; pab < npa * npb; pab += NTEAM) { // this team's bra primitive pairs
+                const int pa = pab / npb, pb = pab - pa * npb;
+                const double ea = ex[off[A] + pa], eb = ex[off[B] + pb], cab = cf[off[A] + pa] * cf[off[B] + pb];
+                if (fabs(cab) * exp(-ea * eb / (ea + eb) * Rab2) < 1e-18) continue; // uniform within the team
+                const double p = ea + eb;
+                const double P[3] = {(ea * RA[0] + eb * RB[0]) / p, (ea * RA[1] + eb * RB[1]) / p, (ea * RA[2] + eb * RB[2]) / p};
+                const double alpha = p * q / (p + q);
+                const double PQ[3] = {P[0] - Q[0], P[1] - Q[1], P[2] - Q[2]};
+                const double pref = two_pi_52 / (p * q * sqrt(p + q)) * cab * ccd;
+                team_sync(); // the team's previous contraction is over: wb, Eab, R tables are free
+                if (tl < 3) hermite_E(la, lb, ea, eb, RA[tl] - RB[tl], Eab + tl * EC_ED);
+                if (tl == (TEAM == EC_T ? 64 : 3)) { // F_n scaled to R^n_000 = (-2 alpha)^n F_n (the host's order of operations)
+                    boys(L, alpha * (PQ[0] * PQ[0] + PQ[1] * PQ[1] + PQ[2] * PQ[2]), F);
+                    double f = 1.0;
+                    for (int n = 0; n <= L; ++n) { F[n] *= f; f *= -2.0 * alpha; }
+                }
+                team_sync();
+                for (int k = tl; k < nab; k += TEAM) {
+                    const int ia = k / ncb, ib = k - ia * ncb;
+                    const int x1 = c_cx[la][ia], x2 = c_cx[lb][ib], y1 = c_cy[la][ia], y2 = c_cy[lb][ib], z1 = c_cz[la][ia], z2 = c_cz[lb][ib];
+                    int n = 0;
+                    for (int t = 0; t <= x1 + x2; ++t) {
+                        const double e1 = pref * Eab[0 * EC_ED + (x1 * 4 + x2) * 7 + t];
+                        for (int u = 0; u <= y1 + y2; ++u) {
+                            const double e2 = e1 * Eab[1 * EC_ED + (y1 * 4 + y2) * 7 + u];
+                            for (int v = 0; v <= z1 + z2; ++v) wb[k * mt + n++] = e2 * Eab[2 * EC_ED + (z1 * 4 + z2) * 7 + v];
                         }
                     }
                 }
+                // R^n_tuv, n = L .. 0 (integrals.c::hermite_R rearranged by auxiliary level): level n holds the orders
+                // t+u+v <= L-n and needs level n+1 only
+                double *cur = Ra, *nxt = Rb;
+                if (tl == 0) cur[0] = F[L];
+                for (int n = L - 1; n >= 0; --n) {
+                    team_sync();
+                    const int smax = L - n, side = smax + 1;
+                    for (int e = tl; e < side * side * side; e += TEAM) {
+                        const int t = e / (side * side), u = (e / side) % side, v = e % side;
+                        const int s = t + u + v;
+                        if (s > smax) continue;
+                        double val;
+                        if (s == 0) {
+                            val = F[n];
+                        } else if (t > 0) {
+                            val = PQ[0] * cur[((t - 1) * RD + u) * RD + v];
+                            if (t > 1) val += (t - 1) * cur[((t - 2) * RD + u) * RD + v];
+                        } else if (u > 0) {
+                            val = PQ[1] * cur[(t * RD + u - 1) * RD + v];
+                            if (u > 1) val += (u - 1) * cur[(t * RD + u - 2) * RD + v];
+                        } else {
+                            val = PQ[2] * cur[(t * RD + u) * RD + v - 1];
+                            if (v > 1) val += (v - 1) * cur[(t * RD + u) * RD + v - 2];
+                        }
+                        nxt[(t * RD + u) * RD + v] = val;
+                    }
+                    double *sw = cur; cur = nxt; nxt = sw;
+                }
+                team_sync(); // `cur` = R^0, wb complete
+#pragma unroll
+                for (int o = 0; o < NACC; ++o) {
+                    int e = tl + o * TEAM;
+                    // opaque to the optimiser: otherwise the index arithmetic of all NACC outputs (kb, kc, four pointers, two
+                    // counts each) is hoisted out of the primitive loops and kept in registers -- 190 of them besides the
+                    // accumulators at NACC = 16, scratch at NACC = 40
+                    if (NACC >= 40) asm volatile("" : "+v"(e));
+                    if (e < nout) {
+                        const int kb = e / ncdc, kc = e - kb * ncdc;
+                        const int n1 = nb[kb], n2 = nk[kc];
+                        const double *w1 = wb + kb * mt, *w2 = wk + kc * mt;
+                        const unsigned short *o1 = ob + kb * mt, *o2 = ok + kc * mt;
+                        double s = 0.0;
+                        for (int i = 0; i < n1; ++i) {
+                            const double *Rm = cur + o1[i];
+                            double g = 0.0;
+                            for (int j = 0; j < n2; ++j) g += w2[j] * Rm[o2[j]];
+                            s += w1[i] * g;
+                        }
+                        acc[o] += s;
+                    }
+                }
+            }
         }
 
-    // Cartesian block -> LDS [ca][cb][cc][cd], rotated in place index by index, scattered
+    // the teams' Cartesian partial sums -> LDS, added in team order into team 0's copy: [ca][cb][cc][cd]
     __syncthreads();
     double *cart = lds;
 #pragma unroll
     for (int o = 0; o < NACC; ++o) {
-        const int e = tid + o * EC_T;
-        if (e < nout) cart[e] = acc[o];
+        const int e = tl + o * TEAM;
+        if (e < nout) cart[(size_t)team * nout + e] = acc[o];
     }
     __syncthreads();
+    if (NTEAM > 1) {
+        for (int e = tid; e < nout; e += EC_T) {
+            double v = cart[e];
+            for (int w = 1; w < NTEAM; ++w) v += cart[(size_t)w * nout + e];
+            cart[e] = v;
+        }
+        __syncthreads();
+    }
+    // rotated in place index by index, scattered
     const int nsa = 2 * la + 1, nsb = 2 * lb + 1, nsc = 2 * lc + 1, nsd = 2 * ld + 1;
     // One index at a time, in place: a thread owns one column of the index being rotated (reads its <= 10 Cartesian
     // entries, writes its <= 7 spherical ones over them); the strides stay the Cartesian ones.
@@ -465,15 +490,18 @@ int DFT_EriColumns(void *h, int C, int D, double screen, unsigned long long d_ou
                 const int mt = std::max(max_terms(l1, l2), mtk);
                 const int L = l1 + l2 + lc + ld, RD = L + 1;
                 const size_t nout = (size_t)nab * ncdc;
-                size_t dbl = 2 * (size_t)RD * RD * RD + (size_t)(nab + ncdc) * mt + 2 * 3 * EC_ED + 16;
+                const int team = (l1 <= 1 && l2 <= 1) ? 64 : EC_T;   // s / p on the bra: a wave per primitive pair
+                const int nteam = EC_T / team;
+                const size_t tp = 2 * (size_t)RD * RD * RD + (size_t)nab * mt + 3 * EC_ED + 16;
+                const size_t dbl = nteam * tp + (size_t)ncdc * mt + 3 * EC_ED;
                 size_t bytes = dbl * 8 + ((size_t)(nab + ncdc) * mt + 1) * 2 + (size_t)(nab + ncdc) * 4 + 16;
-                bytes = std::max(bytes, nout * 8);
+                bytes = std::max(bytes, nteam * nout * 8);
                 bytes = (bytes + 15) & ~(size_t)15;
-                const int nacc = (int)((nout + EC_T - 1) / EC_T);
+                const int nacc = (int)((nout + team - 1) / team);
                 const int *pairs = c->cls_pairs + c->cls_off[cls];
-#define QC_ERI_LAUNCH(N)                                                                                                     \
+#define QC_ERI_LAUNCH(N, TEAMSZ)                                                                                             \
     do {                                                                                                                     \
-        auto kern = k_eri_cols<N>;                                                                                           \
+        auto kern = k_eri_cols<N, TEAMSZ>;                                                                                   \
         static size_t allowed = 48 * 1024;                                                                                   \
         if (bytes > allowed) {                                                                                               \
             if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) { \
@@ -485,12 +513,20 @@ int DFT_EriColumns(void *h, int C, int D, double screen, unsigned long long d_ou
         hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(EC_T), bytes, c->side[nlaunch++ & 3], c->nao, c->xyz, c->ls, c->nprim, c->off, c->ao0, c->ex, \
                            c->cf, c->pA, c->pB, c->qmax, pairs, Cs, Ds, kcd, swap, screen, mt, out);                         \
     } while (0)
-                if (nacc <= 1) QC_ERI_LAUNCH(1);
-                else if (nacc <= 2) QC_ERI_LAUNCH(2);
-                else if (nacc <= 4) QC_ERI_LAUNCH(4);
-                else if (nacc <= 8) QC_ERI_LAUNCH(8);
-                else if (nacc <= 16) QC_ERI_LAUNCH(16);
-                else QC_ERI_LAUNCH(40);
+                if (team == 64) { // nout <= 9 x 100
+                    if (nacc <= 1) QC_ERI_LAUNCH(1, 64);
+                    else if (nacc <= 2) QC_ERI_LAUNCH(2, 64);
+                    else if (nacc <= 4) QC_ERI_LAUNCH(4, 64);
+                    else if (nacc <= 8) QC_ERI_LAUNCH(8, 64);
+                    else QC_ERI_LAUNCH(16, 64);
+                } else {
+                    if (nacc <= 1) QC_ERI_LAUNCH(1, 256);
+                    else if (nacc <= 2) QC_ERI_LAUNCH(2, 256);
+                    else if (nacc <= 4) QC_ERI_LAUNCH(4, 256);
+                    else if (nacc <= 8) QC_ERI_LAUNCH(8, 256);
+                    else if (nacc <= 16) QC_ERI_LAUNCH(16, 256);
+                    else QC_ERI_LAUNCH(40, 256);
+                }
 #undef QC_ERI_LAUNCH
             }
         }
