@@ -153,3 +153,47 @@ def test_water_rhf_sto3g_literature_anchor():
         e, C = eigh(diis.update(S, dm, F), S)
         dm = 2.0 * C[:, :nocc] @ C[:, :nocc].T
     assert E + 8.002367061810450 == pytest.approx(-74.942079928192, abs=2e-8)
+
+
+def test_schwarz_bounds_and_block_pivots_of_the_device_cholesky():
+    """Host-side pieces of the factorisation that feeds on DFT_EriColumns: the Schwarz bounds handed to the device kernel
+    equal sqrt(max (ab|ab)) over each shell pair of the dense tensor, and the per-block pivoted Cholesky that replaces the
+    vector-by-vector loop takes the same pivots and gives the same vectors."""
+    from quantum_compute_dft_amd.cholesky import _block_pivots
+    syms, xyz = basis.parse_xyz("O 0 0 0.1173; H 0 0.7572 -0.4692; H 0 -0.7572 -0.4692")
+    sh = basis.build_shells(syms, np.asarray(xyz), "def2-svp")
+    eri = integrals.int2e(sh)
+    n = sh.nao
+    cols = integrals.EriColumns(sh)
+    diag = cols.diag()
+    cols.close()
+    assert np.allclose(diag, np.einsum("ijij->ij", eri), atol=1e-13)
+    q = integrals.schwarz_bounds(sh, diag)
+    k = 0
+    for a in range(sh.nshell):
+        for b in range(a + 1):
+            a0, a1 = int(sh.ao[a]), int(sh.ao[a]) + 2 * int(sh.l[a]) + 1
+            b0, b1 = int(sh.ao[b]), int(sh.ao[b]) + 2 * int(sh.l[b]) + 1
+            assert q[k] == pytest.approx(np.sqrt(max(0.0, diag[a0:a1, b0:b1].max())), rel=1e-14)
+            k += 1
+    assert k == len(q)
+    # Schwarz: |(ab|cd)| <= q_ab q_cd for every quartet of shells
+    blk = lambda s: slice(int(sh.ao[s]), int(sh.ao[s]) + 2 * int(sh.l[s]) + 1)
+    pid = lambda a, b: a * (a + 1) // 2 + b
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        a, c = sorted(rng.integers(0, sh.nshell, 2))[::-1], sorted(rng.integers(0, sh.nshell, 2))[::-1]
+        v = np.abs(eri[blk(a[0]), blk(a[1]), blk(c[0]), blk(c[1])]).max()
+        assert v <= q[pid(*a)] * q[pid(*c)] * (1 + 1e-12) + 1e-15
+    # block pivots against the sequential loop on a rank-deficient PSD block with trailing columns
+    X = rng.normal(size=(9, 5)); Y = np.vstack([X, rng.normal(size=(6, 5))]); R = X @ Y.T; A = R[:, :9]
+    B, G = _block_pivots(A, 1e-10, 100)
+    res, d, vs, piv = R.copy(), np.diag(A).copy(), [], []
+    while True:
+        b = int(np.argmax(d))
+        if d[b] < 1e-10:
+            break
+        v = res[b] / np.sqrt(d[b]); vs.append(v); piv.append(b); d -= v[:9] ** 2; d[b] = 0.0; res -= np.outer(v[:9], v)
+    assert B == piv and len(B) == 5 and np.allclose(G, np.tril(G))
+    assert np.abs(np.linalg.solve(G, R[B]) - np.array(vs)).max() < 1e-12
+    assert _block_pivots(A, 1e-10, 2)[0] == piv[:2]                      # room for two more vectors only
