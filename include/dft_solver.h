@@ -217,6 +217,47 @@ int DFT_EriColumnsSetStream(void *handle, unsigned long long hip_stream);
 const char *DFT_EriColumnsLastError(void *handle);
 void DFT_EriColumnsClose(void *handle);
 
+/* The rest of an SCF cycle on the device: between the cycle's J / K / Vxc and the next density the
+ * reference's loop runs on the host -- Fock assembly (dft.py:212-223), Pulay DIIS (dft.py:225), eigh(F, S) (dft.py:227),
+ * dm = 2 C_occ C_occ^T (dft.py:228) and the energy traces (dft.py:231-234).  DFT_ScfTailStep queues all of it behind
+ * the kernels that produced J, K and Vxc (csrc/scf_tail.hip): the eigenproblem as the occupied-subspace rotation of
+ * scf.OccupiedRotation from the basis in d_basis.  For 2 <= nao <= 128, 1 <= nocc <= 32 (NULL from Open otherwise).
+ *   Open    hcore, overlap: (nao, nao) device, read in every step; d_basis: (nao, nao) device, columns = an
+ *           S-orthonormal basis whose first nocc columns span the occupied space (the eigenvectors of the last full
+ *           diagonalisation, uploaded by the caller; replaced by the rotated basis after every successful step);
+ *           d_fock_out: (nao, nao) device, receives the DIIS-extrapolated Fock matrix of every step; d_mo_energy:
+ *           nao doubles or 0 (occupied: exact levels of the rotated block, virtual: diagonal estimates).
+ *   Step    rotate = 0: DIIS only (status 1).  c_hf: exact-exchange fraction (K may be 0).  tol: residual at which the
+ *           rotation's fixed point stops; canon_tol: the Jacobi sweeps that make the occupied block diagonal end with
+ *           the first sweep that met no column pair with |cos| above it (the pairs are then below ~canon_tol^2;
+ *           <= 0: 1e-3); max_inner: fixed-point steps allowed (<= 0: 60).  slot: ring slot (0..7) that
+ *           receives this cycle's (F, e); hist: the nhist <= 8 live slots, `slot` among them; coef: NULL, or the nhist
+ *           Pulay coefficients to use instead of solving for them.  d_J, d_K, d_vraw: this cycle's matrices (vraw as
+ *           DFT_ComputeXC leaves it: symmetrised here, dft.py:212); d_dm (nao, nao), d_cocc (nao, nocc) with
+ *           dm = cocc cocc^T: the CURRENT density in, the NEXT one out (status 0 only).  d_exc: 0, or the device scalar
+ *           a DFT_ComputeXC*Async call queued before this step writes: Wait then returns it as out[7], and the whole
+ *           cycle needs one host wait.
+ *   Finish  after status 1: the caller has diagonalised d_fock_out and put the eigenvectors into d_basis; writes
+ *           cocc = sqrt(2) basis[:, :nocc], dm and the traces.
+ *   Wait    blocks (polling host-mapped memory) until the last Step / Finish has completed; out[0..6] = tr(dm' Hcore),
+ *           tr(dm' J)/2, -c_hf tr(dm' K)/4, |dm' - dm|_F, status, fixed-point steps, Jacobi sweeps, Exc (see d_exc).  status 0: done;
+ *           1: diagonalise d_fock_out yourself, then Finish; 2: the DIIS system was singular (DFT_ScfTailGram copies the
+ *           8 x 8 Gram matrix of the ring to the host: solve it there and repeat the Step with `coef`).
+ * Everything is asynchronous on the handle's stream except Wait and Gram.  0 on success, -1 on error. */
+void *DFT_ScfTailOpen(int nao, int nocc, unsigned long long d_hcore, unsigned long long d_overlap, unsigned long long d_basis,
+                      unsigned long long d_fock_out, unsigned long long d_mo_energy);
+int DFT_ScfTailSetStream(void *handle, unsigned long long hip_stream);
+int DFT_ScfTailStep(void *handle, int rotate, double c_hf, double tol, double canon_tol, int max_inner, int slot, int nhist,
+                    const int *hist, const double *coef, unsigned long long d_J, unsigned long long d_K,
+                    unsigned long long d_vraw, unsigned long long d_dm, unsigned long long d_cocc, unsigned long long d_exc);
+int DFT_ScfTailFinish(void *handle, double c_hf, unsigned long long d_J, unsigned long long d_K, unsigned long long d_dm,
+                      unsigned long long d_cocc);
+int DFT_ScfTailWait(void *handle, double *out8);
+int DFT_ScfTailGram(void *handle, double *host_out64);
+int DFT_ScfTailStamps(void *handle, long long *host_out16);   /* diagnostics: 100 MHz stamps of the rotation kernel's phases */
+const char *DFT_ScfTailLastError(void *handle);
+void DFT_ScfTailClose(void *handle);
+
 /* Options: "quirks" (1 = reference formulas as shipped, default; 0 = corrected
  * VWN5 / PBE-c derivatives), "path" (0 = auto: wave-specialised
  * persistent MFMA kernels for nao <= 128, generic MFMA kernels above; 1 =
@@ -228,7 +269,9 @@ void DFT_EriColumnsClose(void *handle);
  * fewer: DFT_ComputeXC may then return while that kernel's last blocks still store Vxc, which only
  * consumers on the solver's own stream are ordered behind), "strict_sync" (with fuse_finish = 1: 1 =
  * DFT_ComputeXC also waits for the stream to report complete before returning), "occ" (DFT_ComputeXCOcc:
- * 0 = auto, 1 = always the occupied-orbital density step, 2 = never), "ao_pt" (grid points per workgroup of DFT_EvalAO:
+ * 0 = auto, 1 = always the occupied-orbital density step, 2 = never), "graph" (the synchronous calls: -1 = auto, default:
+ * a call repeated with the same pointers and sizes is replayed as one recorded HIP graph where it is launch-bound,
+ * planes of at most 2e6 doubles; 1 = always; 0 = never.  Same kernels, same results bit for bit), "ao_pt" (grid points per workgroup of DFT_EvalAO:
  * 8, 16, or 0 = auto), "rho_rows" (grid rows per workgroup of the large-basis
  * density kernel: 64, default, or 128).  Returns 0 if the key is known. */
 int DFT_SetOption(XCSolver *solver, const char *key, double value);

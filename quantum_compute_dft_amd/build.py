@@ -26,7 +26,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdft.so")
 STAMP_PATH = LIB_PATH + ".srchash"
-SOURCES = ["dft_api.hip", "xc_occ.hip", "eri_cols.hip"]   # one object each, compiled in parallel, linked into libdft.so
+SOURCES = ["dft_api.hip", "xc_occ.hip", "eri_cols.hip", "scf_tail.hip"]   # one object each, compiled in parallel, linked into libdft.so
 HEADERS = ["xc_functionals.hpp", "xc_kernels.hpp", "xc_ws_kernels.hpp", "xc_ws16_kernels.hpp", "xc_big_kernels.hpp",
            "xc_occ_kernels.hpp", "xc_occ_launch.hpp", "jk_kernels.hpp", "ao_kernels.hpp", "cd_kernels.hpp", "device_util.hpp",
            os.path.join("..", "..", "include", "dft_solver.h")]

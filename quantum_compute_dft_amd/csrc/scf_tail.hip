@@ -1,0 +1,936 @@
+// The part of an SCF cycle between the Fock contributions and the next density, on the device in six launches:
+// what dft.py:212-236 does on the host with numpy (Fock assembly, DIIS, eigh(F, S), density, energy terms) and what
+// scf.py's host loop spent 0.44 of a 0.93 ms Benzene cycle on (profiles/r03_scf_host_parts.txt: transfers 0.06,
+// Fock 0.02, DIIS 0.07, occupied-subspace rotation 0.26, density + energies 0.03).  J, K and Vxc are already in HBM
+// when the cycle's kernels finish; nothing but six scalars and a status word crosses PCIe afterwards.
+//
+//   k_tail_fock     F = H + J + (V + V^T)/2 - c_hf K/2 into the DIIS ring; F c and S c (c = occupied orbitals, dm = c c^T)
+//   k_tail_err      e = F D S - S D F through the thin factors, into the ring; one new row of the DIIS Gram matrix
+//   k_tail_mix      Pulay coefficients (a <= 9 x 9 system, per workgroup), F_ext = sum c_k F_k, F_ext U
+//   k_tail_a        A = U^T (F_ext U)
+//   k_tail_rot      ONE workgroup: the rotation K (n_virt x n_occ) that block-diagonalises A, by the diagonally
+//                   preconditioned fixed point of scf.OccupiedRotation; the new S-orthonormal basis
+//                       U_o' = (U_o + U_v K) L^-T V,   L L^T = 1 + K^T K,   V: Jacobi rotations that make L^-1 F_o L^-T diagonal
+//                       U_v' = T + (T K) X K^T,        T = U_v - U_o K^T,   X = -L^-T (1 + L)^-1
+//                   (the Cholesky form of the completion: no eigen-decomposition of K^T K, and
+//                    (1 + K X^T K^T)(1 + K K^T)(1 + K X K^T) = 1 exactly)
+//   k_tail_density  dm' = c' c'^T, tr(dm' H), tr(dm' J)/2, -c_hf tr(dm' K)/4, |dm' - dm|; the last workgroup adds the
+//                   row partials in a fixed order and publishes them to host-mapped memory
+//
+// A cycle whose rotation is refused (first-order step above 0.5, no convergence, aufbau order in doubt) or that has
+// no basis yet reports status 1 and leaves F_ext in the caller's buffer: the caller diagonalises it (LAPACK or
+// hipSOLVER, as scf.OccupiedRotation._exact does), uploads the basis and calls DFT_ScfTailFinish.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/dft_solver.h"
+#include "device_util.hpp"
+
+using namespace qcdft;
+
+namespace {
+
+constexpr int TL_MAXN = 128;   // basis functions (LDS rows of the strip kernels, diagonal in k_tail_rot)
+constexpr int TL_MAXO = 32;    // occupied orbitals (one wave per Jacobi pair, LDS copies of the small matrices)
+constexpr int TL_SPACE = 8;    // DIIS ring
+constexpr int TL_ROT_T = 512;  // threads of k_tail_rot (eight waves: 256 registers each)
+constexpr int TL_LD = TL_MAXO + 1;
+
+struct TailArgs {
+    int n, no, slot, nhist, have_coef, rotate, max_inner;
+    int hist[TL_SPACE];
+    double coef[TL_SPACE];
+    double c_hf, tol, canon_tol;
+};
+
+struct RotLds {   // offsets (doubles) into the rotation kernel's dynamic LDS; -1 = the matrix stays in memory
+    int km, bm, qm, rm, smalls;
+};
+
+struct TailDev {
+    int n = 0, no = 0;
+    const double *H = nullptr, *S = nullptr;
+    double *U = nullptr, *Fx = nullptr, *eig = nullptr;       // caller's
+    double *blob = nullptr;                                   // everything below
+    double *Fb, *Eb, *Gb, *FC, *SC, *gpart, *FU, *A, *Unew, *Km, *Rm, *Qm, *Bm, *epart;
+    int *status = nullptr;     // [0] status, [1] inner steps, [2] Jacobi sweeps, [3] ticket
+    double *h_out = nullptr, *h_out_dev = nullptr;            // host-mapped: 8 doubles + sequence word
+    unsigned long seq = 0;
+    RotLds lo{-1, -1, -1, -1, 0}; // where the fixed point's matrices live
+    unsigned rot_lds = 0;      // dynamic LDS bytes of k_tail_rot
+    hipStream_t stream = nullptr;
+    char err[256] = {0};
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// value of `v` in lane `l` (wave-uniform l), through SGPRs: no LDS crossbar
+__device__ __forceinline__ double bcast(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// F row i into ring slot `slot`; (F c)[i, :] and (S c)[i, :].  Thread (o, q): orbital o, quarter... eighth q of the j range.
+__global__ __launch_bounds__(256) void k_tail_fock(TailArgs a, const double *__restrict__ H, const double *__restrict__ S,
+                                                   const double *__restrict__ J, const double *__restrict__ Kx,
+                                                   const double *__restrict__ V, const double *__restrict__ c,
+                                                   double *__restrict__ Fb, double *__restrict__ FC, double *__restrict__ SC,
+                                                   int *__restrict__ status)
+{
+    __shared__ double frow[TL_MAXN], srow[TL_MAXN], pf[8][TL_MAXO], ps[8][TL_MAXO];
+    const int n = a.n, no = a.no, i = blockIdx.x, t = threadIdx.x;
+    if (i == 0 && t == 0) { status[0] = 0; status[1] = 0; status[2] = 0; }   // read by the kernels behind this one only
+    double *F = Fb + (size_t)a.slot * n * n;
+    if (t < n) {
+        const int j = t;
+        double f = H[i * n + j] + J[i * n + j] + 0.5 * (V[i * n + j] + V[j * n + i]);   // dft.py:212,223
+        if (Kx) f -= 0.5 * a.c_hf * Kx[i * n + j];                                     // dft.py:221
+        F[i * n + j] = f;
+        frow[j] = f;
+        srow[j] = S[i * n + j];
+    }
+    __syncthreads();
+    const int o = t & 31, q = t >> 5, per = (n + 7) >> 3, j0 = q * per, j1 = min(n, j0 + per);
+    double fc = 0.0, sc = 0.0;
+    if (o < no)
+        for (int j = j0; j < j1; ++j) {
+            const double cj = c[j * no + o];
+            fc = fma(frow[j], cj, fc);
+            sc = fma(srow[j], cj, sc);
+        }
+    pf[q][o] = fc;
+    ps[q][o] = sc;
+    __syncthreads();
+    if (t < no) {
+        double x = 0.0, y = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { x += pf[k][t]; y += ps[k][t]; }
+        FC[i * no + t] = x;
+        SC[i * no + t] = y;
+    }
+}
+
+// e[i, j] = (F D S - S D F)[i, j] with D = c c^T: sum_o FC[i,o] SC[j,o] - SC[i,o] FC[j,o]   (scf.CDIIS: sdf^T - sdf);
+// partial Gram row: gpart[i][s] = sum_j Eb[hist[s]][i, j] e[i, j]
+__global__ __launch_bounds__(128) void k_tail_err(TailArgs a, const double *__restrict__ FC, const double *__restrict__ SC,
+                                                  double *__restrict__ Eb, double *__restrict__ gpart)
+{
+    __shared__ double fci[TL_MAXO], sci[TL_MAXO], part[2][TL_SPACE];
+    const int n = a.n, no = a.no, i = blockIdx.x, t = threadIdx.x;
+    if (t < TL_MAXO) { fci[t] = t < no ? FC[i * no + t] : 0.0; sci[t] = t < no ? SC[i * no + t] : 0.0; }
+    __syncthreads();
+    double *E = Eb + (size_t)a.slot * n * n;
+    double e = 0.0;
+    const int j = t;
+    if (j < n) {
+        double sj[TL_MAXO], fj[TL_MAXO];
+#pragma unroll
+        for (int o = 0; o < TL_MAXO; ++o) {   // every load first: one memory round trip, not n_occ of them
+            sj[o] = o < no ? SC[j * no + o] : 0.0;
+            fj[o] = o < no ? FC[j * no + o] : 0.0;
+        }
+#pragma unroll
+        for (int o = 0; o < TL_MAXO; ++o) e += fci[o] * sj[o] - sci[o] * fj[o];
+        E[i * n + j] = e;
+    }
+    double eh[TL_SPACE];
+#pragma unroll
+    for (int s = 0; s < TL_SPACE; ++s) {
+        const int h = a.hist[s < a.nhist ? s : 0];
+        eh[s] = (s < a.nhist && j < n) ? (h == a.slot ? e : Eb[(size_t)h * n * n + (size_t)i * n + j]) : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < TL_SPACE; ++s) {
+        const double p = wave_sum(eh[s] * e);
+        if ((t & 63) == 0) part[t >> 6][s] = p;
+    }
+    __syncthreads();
+    if (t < a.nhist) gpart[i * TL_SPACE + t] = part[0][t] + part[1][t];
+}
+
+// Pulay coefficients (every workgroup solves the same <= 9 x 9 system, one row per lane, in registers) and row i of
+// F_ext = sum_k c_k F_k.  status[0] = 2 if the system is singular.
+__global__ __launch_bounds__(128) void k_tail_mix(TailArgs a, const double *__restrict__ gpart, double *__restrict__ Gb,
+                                                  const double *__restrict__ Fb, double *__restrict__ Fx, int *__restrict__ status)
+{
+    __shared__ double cf[TL_SPACE];
+    __shared__ int bad;
+    const int n = a.n, t = threadIdx.x, i = blockIdx.x, m = a.nhist, lane = t & 63;
+    if (t == 0) bad = 0;
+    if (t < 64) {
+        // the new Gram row: a fixed summation tree (every workgroup gets the same bits)
+        double gs[TL_SPACE];
+#pragma unroll
+        for (int s = 0; s < TL_SPACE; ++s) {
+            double p = 0.0;
+            if (s < m)
+                for (int r = lane; r < n; r += 64) p += gpart[r * TL_SPACE + s];
+            gs[s] = wave_sum(p);
+        }
+        if (i == 0 && lane == 0)   // the ring's Gram matrix: row and column of the new slot (nobody reads those entries from memory here)
+            for (int s = 0; s < m; ++s) Gb[a.slot * TL_SPACE + a.hist[s]] = Gb[a.hist[s] * TL_SPACE + a.slot] = gs[s];
+        if (a.have_coef) {
+            if (lane < m) cf[lane] = a.coef[lane];
+        } else if (m < 2) {
+            if (lane == 0) cf[0] = 1.0;
+        } else {
+            // B = [[0, 1^T], [1, G]], B x = e_0 (scf.CDIIS.update): Gaussian elimination with partial pivoting; lane p holds
+            // row p and never moves it -- the pivot of step k is the largest |B[p][k]| among the rows not yet used
+            const int d = m + 1;
+            double row[TL_SPACE + 2];
+            // lane p >= 1 is history entry p - 1; entries of the new slot's row / column come from this cycle's sums
+            const int hp = a.hist[lane >= 1 && lane < d ? lane - 1 : 0];
+            double gmine = 0.0;                                   // gs[lane - 1]
+#pragma unroll
+            for (int s = 0; s < TL_SPACE; ++s) gmine = s == lane - 1 ? gs[s] : gmine;
+#pragma unroll
+            for (int qq = 0; qq <= TL_SPACE; ++qq) {
+                double v = 0.0;
+                if (lane < d && qq < d) {
+                    if (lane == 0 && qq == 0) v = 0.0;
+                    else if (lane == 0 || qq == 0) v = 1.0;
+                    else {
+                        const int hq = a.hist[qq - 1];
+                        v = hp == a.slot ? gs[qq - 1] : hq == a.slot ? gmine : Gb[hp * TL_SPACE + hq];
+                    }
+                }
+                row[qq] = v;
+            }
+            row[TL_SPACE + 1] = lane == 0 ? 1.0 : 0.0;   // right-hand side
+            bool used = false, sing = false;
+            int order = -1;
+#pragma unroll
+            for (int k = 0; k <= TL_SPACE; ++k) {
+                if (k < d && !sing) {
+                    const double cand = (!used && lane < d) ? fabs(row[k]) : -1.0;
+                    const double mx = wave_max(cand);
+                    if (!(mx > 0.0)) { sing = true; }
+                    else {
+                        const int piv = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(cand == mx)) - 1);
+                        double pr[TL_SPACE + 2];
+#pragma unroll
+                        for (int qq = 0; qq <= TL_SPACE + 1; ++qq) pr[qq] = bcast(row[qq], piv);
+                        if (lane == piv) { used = true; order = k; }
+                        else if (!used && lane < d) {
+                            const double f = row[k] / pr[k];
+#pragma unroll
+                            for (int qq = 0; qq <= TL_SPACE + 1; ++qq) row[qq] -= f * pr[qq];
+                        }
+                    }
+                }
+            }
+            double x[TL_SPACE + 1];
+#pragma unroll
+            for (int k = 0; k <= TL_SPACE; ++k) x[k] = 0.0;
+            if (!sing) {
+#pragma unroll
+                for (int k = TL_SPACE; k >= 0; --k) {
+                    if (k < d) {
+                        const int own = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(order == k)) - 1);
+                        double sacc = row[TL_SPACE + 1];
+#pragma unroll
+                        for (int qq = 0; qq <= TL_SPACE; ++qq)
+                            if (qq > k && qq < d) sacc -= row[qq] * x[qq];
+                        x[k] = bcast(sacc / row[k], own);
+                        if (!(fabs(x[k]) < 1e300)) sing = true;   // inf / NaN
+                    }
+                }
+            }
+            if (sing) { if (lane == 0) bad = 1; }
+            else {
+#pragma unroll
+                for (int k = 1; k <= TL_SPACE; ++k)
+                    if (lane == 0 && k < d) cf[k - 1] = x[k];
+            }
+        }
+    }
+    __syncthreads();
+    if (bad) {
+        if (i == 0 && t == 0) status[0] = 2;
+        return;
+    }
+    if (t < n) {
+        double fb[TL_SPACE];
+#pragma unroll
+        for (int s = 0; s < TL_SPACE; ++s) fb[s] = s < m ? Fb[(size_t)a.hist[s] * n * n + (size_t)i * n + t] : 0.0;
+        double f = 0.0;
+#pragma unroll
+        for (int s = 0; s < TL_SPACE; ++s)
+            if (s < m) f = fma(cf[s], fb[s], f);
+        Fx[i * n + t] = f;
+    }
+}
+
+// One 16 x 16 tile of C (M x N) = A B per workgroup on the fp64 matrix cores, the contraction split over four waves
+// (K <= 128: at most eight steps of four each, all operands loaded before the first MFMA): A(i, k) = a[i ars + k acs],
+// B(k, j) = b[k brs + j bcs].
+__global__ __launch_bounds__(256) void k_tail_gemm(int M, int N, int Kd, const double *__restrict__ a, int ars, int acs,
+                                                   const double *__restrict__ b, int brs, int bcs, double *__restrict__ c, int ldc,
+                                                   const int *__restrict__ status)
+{
+    __shared__ double part[4][4][64];
+    if (status[0] != 0) return;
+    const int nt = (N + 15) >> 4, tile = blockIdx.x, i0 = (tile / nt) << 4, j0 = (tile % nt) << 4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+    const int ia = i0 + li, jb = j0 + li;
+    const bool aok = ia < M, bok = jb < N;
+    double av[8], bv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int k = 4 * (4 * s + wave) + kq;
+        av[s] = aok && k < Kd ? a[(size_t)ia * ars + (size_t)k * acs] : 0.0;
+        bv[s] = bok && k < Kd ? b[(size_t)k * brs + (size_t)jb * bcs] : 0.0;
+    }
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = mfma_f64(av[s], bv[s], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = i0 + kq + 4 * r, col = j0 + li;
+            if (row < M && col < N) c[(size_t)row * ldc + col] = (part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane]);
+        }
+    }
+}
+
+// C (M x N, ldc) = alpha sum_k A(i, k) B(k, j) + beta D(i, j) by the whole workgroup on the fp64 matrix cores, one 16 x 16 tile
+// per wave at a time; A(i, k) = a[i ars + k acs], B(k, j) = b[k brs + j bcs] -- transposes are strides; operands in LDS or
+// memory (generic pointers), eight contraction steps' worth loaded ahead of their MFMAs.  The caller puts a barrier
+// between dependent products.
+__device__ void wg_gemm(int M, int N, int Kd, const double *a, int ars, int acs, const double *b, int brs, int bcs,
+                        double alpha, double beta, const double *d, int ldd, double *c, int ldc)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int mt = (M + 15) >> 4, nt = (N + 15) >> 4;
+    const int li = lane & 15, kq = lane >> 4;
+    for (int tile = wave; tile < mt * nt; tile += nwave) {
+        const int i0 = (tile / nt) << 4, j0 = (tile % nt) << 4;
+        const int ia = i0 + li, jb = j0 + li;
+        const bool aok = ia < M, bok = jb < N;
+        const double *ap = a + (size_t)(aok ? ia : 0) * ars, *bp = b + (size_t)(bok ? jb : 0) * bcs;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < Kd; k0 += 32) {
+            double av[8], bv[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int k = k0 + 4 * s + kq;
+                const bool kok = k < Kd;
+                av[s] = aok && kok ? ap[(size_t)k * acs] : 0.0;
+                bv[s] = bok && kok ? bp[(size_t)k * brs] : 0.0;
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = mfma_f64(av[s], bv[s], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = i0 + kq + 4 * r, col = j0 + li;
+            if (row < M && col < N) {
+                double v = alpha * acc[r];
+                if (beta != 0.0) v += beta * d[(size_t)row * ldd + col];
+                c[(size_t)row * ldc + col] = v;
+            }
+        }
+    }
+}
+
+__device__ double block_max(double v, double *scratch)
+{
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double m = scratch[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmax(m, scratch[w]);
+    return m;
+}
+
+// sum over the (at most 32) lanes of a wave that hold a column's rows; every lane gets the total
+__device__ __forceinline__ double half_sum(double v)
+{
+    v = row16_sum(v);
+    return bcast(v, 0) + bcast(v, 16);
+}
+
+// Cholesky P = L L^T in the registers of wave 0 (lane i holds row i; the trailing update takes L[k][j] from lane k),
+// then L^-1 (wave 0) and (1 + L)^-1 (wave 1), one column per lane by forward substitution.
+__device__ __forceinline__ void chol_and_inverses(int no, const double *Pm, double (*Lm)[TL_LD], double (*Li)[TL_LD], double (*L1)[TL_LD])
+{
+    const int t = threadIdx.x;
+    if (t < 64) {
+        const int lane = t;
+        double r[TL_MAXO];
+#pragma unroll
+        for (int j = 0; j < TL_MAXO; ++j)
+            r[j] = (lane < no && j < no) ? 0.5 * (Pm[lane * no + j] + Pm[j * no + lane]) + (lane == j ? 1.0 : 0.0) : (lane == j ? 1.0 : 0.0);
+#pragma unroll
+        for (int j = 0; j < TL_MAXO; ++j) {
+            if (j < no) {
+                const double djj = sqrt(bcast(r[j], j));
+                r[j] = lane == j ? djj : (lane > j ? r[j] / djj : 0.0);
+#pragma unroll
+                for (int k = j + 1; k < TL_MAXO; ++k)
+                    if (k < no) r[k] -= r[j] * bcast(r[j], k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TL_MAXO; ++j)
+            if (lane < TL_MAXO) Lm[lane][j] = j <= lane ? r[j] : 0.0;
+    }
+    __syncthreads();
+    if (t < 128) {
+        const int lane = t & 63;
+        const bool plus = t >= 64;
+        double x[TL_MAXO];
+#pragma unroll
+        for (int i = 0; i < TL_MAXO; ++i) {
+            double s = lane == i ? 1.0 : 0.0;
+            x[i] = lane == i ? 1.0 : 0.0;                                    // rows past n_occ: the identity
+            if (i < no) {
+#pragma unroll
+                for (int k = 0; k < i; ++k) s -= Lm[i][k] * x[k];      // uniform LDS addresses: broadcast reads; x[k] = 0 above the diagonal
+                x[i] = lane <= i ? s / (Lm[i][i] + (plus ? 1.0 : 0.0)) : 0.0;   // (1 + L) has the same strictly lower part
+            }
+            __builtin_amdgcn_sched_barrier(0);                               // row by row: hoisting every row's loads costs registers
+        }
+        double (*Out)[TL_LD] = plus ? L1 : Li;
+#pragma unroll
+        for (int i = 0; i < TL_MAXO; ++i)
+            if (lane < TL_MAXO) Out[i][lane] = x[i];
+    }
+    __syncthreads();
+}
+
+// 1 / x and 1 / sqrt(x) from the hardware estimates plus one Newton step (the Jacobi rotations need c^2 + s^2 = 1 to
+// rounding, not correctly rounded quotients; the library division and square root are ~25 instructions each)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    return y * fma(-0.5 * x * y, y, 1.5);
+}
+
+__global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, const double *__restrict__ A, const double *__restrict__ U,
+                                                       double *Km_g, double *Rm_g, double *Qm_g, double *Bm_g, double *W,
+                                                       double *eig, int *status, long long *stamps)
+{
+#define QCDFT_STAMP(k) do { if (threadIdx.x == 0) stamps[k] = (long long)wall_clock64(); } while (0)
+    // dynamic LDS: [A (n x n) during the fixed point | the completion's small matrices afterwards][K][B][Q][R] as they fit
+    extern __shared__ double dyn[];
+    __shared__ double dd[TL_MAXN], red[TL_ROT_T / 64];
+    __shared__ int flag[TL_ROT_T / 64];
+    const int n = a.n, no = a.no, nv = n - no, t = threadIdx.x, nk = nv * no;
+    if (status[0] != 0) return;   // the DIIS system was singular: nothing to rotate
+    QCDFT_STAMP(0);
+    double *As = dyn;
+    double *Km = lo.km >= 0 ? dyn + lo.km : Km_g, *Bm = lo.bm >= 0 ? dyn + lo.bm : Bm_g, *Qm = lo.qm >= 0 ? dyn + lo.qm : Qm_g,
+           *Rm = lo.rm >= 0 ? dyn + lo.rm : Rm_g;
+    for (int e0 = 0; e0 < n * n; e0 += 8 * TL_ROT_T) {   // eight loads in flight per thread
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = e0 + k * TL_ROT_T + t < n * n ? A[e0 + k * TL_ROT_T + t] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (e0 + k * TL_ROT_T + t < n * n) As[e0 + k * TL_ROT_T + t] = v[k];
+    }
+    __syncthreads();
+    const double *Aoo = As, *Aov = As + no, *Avo = As + (size_t)no * n, *Avv = As + (size_t)no * n + no;
+    if (t < n) dd[t] = As[(size_t)t * n + t];
+    __syncthreads();
+    // this thread's elements of K (e = t, t + 512, ...): their denominators stay in registers
+    constexpr int EPT = (TL_MAXN * TL_MAXO + TL_ROT_T - 1) / TL_ROT_T;   // nv no < 128 * 32
+    double rd[EPT];
+    double kmax = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = t + k * TL_ROT_T;
+        rd[k] = 0.0;
+        if (e < nk) {
+            const int v = e / no, o = e - v * no;
+            rd[k] = 1.0 / (dd[no + v] - dd[o]);
+            const double x = -Avo[(size_t)v * n + o] * rd[k];
+            Km[e] = x;
+            kmax = fmax(kmax, fabs(x));
+            if (!(fabs(x) <= 0.5)) kmax = 1.0;   // NaN too
+        }
+    }
+    kmax = block_max(kmax, red);
+    if (!(kmax <= 0.5)) {
+        if (t == 0) status[0] = 1;
+        return;
+    }
+    QCDFT_STAMP(1);
+    // fixed point K <- K - R / (a_v - a_o),  R = Avo + Avv K - K (Aoo + Aov K)    (scf.OccupiedRotation)
+    double prev = INFINITY;
+    bool ok = false;
+    int steps = 0;
+    for (int it = 0; it < a.max_inner; ++it) {
+        wg_gemm(nv, no, nv, Avv, n, 1, Km, no, 1, 1.0, 1.0, Avo, n, Qm, no);
+        wg_gemm(no, no, nv, Aov, n, 1, Km, no, 1, 1.0, 1.0, Aoo, n, Bm, no);
+        __syncthreads();
+        if (it == 0) QCDFT_STAMP(2);
+        wg_gemm(nv, no, no, Km, no, 1, Bm, no, 1, -1.0, 1.0, Qm, no, Rm, no);
+        __syncthreads();
+        if (it == 0) QCDFT_STAMP(3);
+        double r = 0.0, rv[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = t + k * TL_ROT_T;
+            rv[k] = e < nk ? Rm[e] : 0.0;
+            const double x = fabs(rv[k]);
+            r = fmax(r, x);
+            if (!(x == x)) r = INFINITY;
+        }
+        r = block_max(r, red);
+        ++steps;
+        if (r < a.tol) { ok = true; break; }
+        if (!(r < 4.0 * prev)) break;   // diverging (or NaN)
+        prev = fmin(prev, r);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = t + k * TL_ROT_T;
+            if (e < nk) Km[e] -= rv[k] * rd[k];
+        }
+        __syncthreads();
+        if (it == 0) QCDFT_STAMP(4);
+    }
+    QCDFT_STAMP(5);
+    if (t == 0) status[1] = steps;
+    if (!ok) {
+        if (t == 0) status[0] = 1;
+        return;
+    }
+    // The completion's small matrices: A's space is free now (K, B, Q stay where they are).
+    const int n2o = no * no;
+    double *sp = dyn + lo.smalls;
+    double (*Lm)[TL_LD] = (double (*)[TL_LD])sp, (*Li)[TL_LD] = (double (*)[TL_LD])(sp + TL_MAXO * TL_LD),
+           (*L1)[TL_LD] = (double (*)[TL_LD])(sp + 2 * TL_MAXO * TL_LD), (*Wc)[TL_LD] = (double (*)[TL_LD])(sp + 3 * TL_MAXO * TL_LD),
+           (*Vc)[TL_LD] = (double (*)[TL_LD])(sp + 4 * TL_MAXO * TL_LD);
+    double *cm = sp + 5 * TL_MAXO * TL_LD;
+    double *Fo = cm, *Pm = cm + n2o, *W1 = cm + 2 * n2o, *Fop = cm + 3 * n2o, *Vo = cm + 4 * n2o, *cd = cm + 5 * n2o, *Xm = cm + 6 * n2o,
+           *Lig = cm + 7 * n2o, *L1g = cm + 8 * n2o, *MX = cm + 9 * n2o;
+    // Fo = Y^T F Y in the U basis (Y = Uo + Uv K), M = K^T K (P = Y^T Y = 1 + M)
+    wg_gemm(no, no, nv, Km, 1, no, Qm, no, 1, 1.0, 1.0, Bm, no, Fo, no);
+    wg_gemm(no, no, nv, Km, 1, no, Km, no, 1, 1.0, 0.0, nullptr, 0, Pm, no);
+    __syncthreads();
+    QCDFT_STAMP(6);
+    chol_and_inverses(no, Pm, Lm, Li, L1);
+    QCDFT_STAMP(7);
+    for (int e = t; e < n2o; e += TL_ROT_T) {
+        const int i = e / no, j = e - i * no;
+        Lig[e] = Li[i][j];
+        L1g[e] = L1[i][j];
+    }
+    __syncthreads();
+    // G = L^-1 Fo L^-T
+    wg_gemm(no, no, no, Lig, no, 1, Fo, no, 1, 1.0, 0.0, nullptr, 0, W1, no);
+    __syncthreads();
+    wg_gemm(no, no, no, W1, no, 1, Lig, 1, no, 1.0, 0.0, nullptr, 0, Fop, no);
+    __syncthreads();
+    QCDFT_STAMP(8);
+    // One-sided Jacobi on the columns of G - sigma (sigma above the spectrum: all eigenvalues of one sign, so orthogonal
+    // columns of (G - sigma) V are eigenvectors of G itself).  Half a wave per column pair (lane = row), the pairs of a
+    // round by the circle method; a pair whose columns are already orthogonal to a tenth of the tolerance is left alone.
+    const int ne = (no + 1) & ~1;
+    {
+        double gs = 0.0;
+        if (t < no) {
+            double rs = 0.0;
+            for (int j = 0; j < no; ++j) rs += fabs(0.5 * (Fop[t * no + j] + Fop[j * no + t]));
+            gs = rs;
+        }
+        const double sigma = block_max(gs, red) + 1.0;   // Gershgorin bound on |lambda|, plus a margin
+        for (int e = t; e < TL_MAXO * TL_MAXO; e += TL_ROT_T) {
+            const int j = e / TL_MAXO, i = e - j * TL_MAXO;   // column j, row i
+            double g = 0.0;
+            if (i < no && j < no) g = 0.5 * (Fop[i * no + j] + Fop[j * no + i]) - (i == j ? sigma : 0.0);
+            Wc[j][i] = g;
+            Vc[j][i] = i == j ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        const int wave = t >> 6, lane = t & 63, npair = ne >> 1, row = lane & 31;
+        // Rotations converge quadratically: a sweep that met no pair with |cos| above canon_tol leaves all of them below
+        // ~canon_tol^2, which ends the iteration (canon_tol 1e-3: an occupied block diagonal to ~1e-6 of its scale -- the
+        // next cycle's denominators want no more, and the orbitals are exactly orthonormal whatever the rotations were).
+        const double stop2 = a.canon_tol * a.canon_tol, skip2 = 1e-26;
+        int sweeps = 0;
+        for (int sweep = 0; sweep < 12; ++sweep) {
+            int big = 0;
+            for (int round = 0; round < ne - 1; ++round) {
+                const int pr = 2 * wave + (lane >> 5);   // sixteen pairs at a time
+                if (2 * wave < npair) {
+                    const bool live = pr < npair && row < ne;
+                    // circle method: position 0 is held by column ne - 1, the others rotate
+                    const int p = !live ? 0 : pr == 0 ? ne - 1 : (round + pr) % (ne - 1);
+                    const int q = !live ? 0 : pr == 0 ? round : (round - pr + (ne - 1)) % (ne - 1);
+                    const double wp = live ? Wc[p][row] : 0.0, wq = live ? Wc[q][row] : 0.0;
+                    const double vp = live ? Vc[p][row] : 0.0, vq = live ? Vc[q][row] : 0.0;
+                    double al = row16_sum(wp * wp), be = row16_sum(wq * wq), ga = row16_sum(wp * wq);
+                    al += __shfl_xor(al, 16, 64); be += __shfl_xor(be, 16, 64); ga += __shfl_xor(ga, 16, 64);   // the pair's 32 lanes
+                    const double g2 = ga * ga, ab = al * be;
+                    if (live && g2 > skip2 * ab) {
+                        big |= g2 > stop2 * ab;
+                        const double zeta = 0.5 * (be - al) * fast_rcp(ga);
+                        const double az = fabs(zeta);
+                        const double hyp = az < 1e150 ? (1.0 + zeta * zeta) * fast_rsqrt(1.0 + zeta * zeta) : az;   // sqrt(1 + zeta^2)
+                        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * fast_rcp(az + hyp);
+                        const double cs = fast_rsqrt(1.0 + tt * tt), sn = cs * tt;
+                        Wc[p][row] = cs * wp - sn * wq;
+                        Wc[q][row] = sn * wp + cs * wq;
+                        Vc[p][row] = cs * vp - sn * vq;
+                        Vc[q][row] = sn * vp + cs * vq;
+                    }
+                }
+                __syncthreads();
+            }
+            ++sweeps;
+            const int any = __ballot(big) != 0;
+            if (lane == 0) flag[wave] = any;
+            __syncthreads();
+            int more = 0;
+            for (int k = 0; k < TL_ROT_T / 64; ++k) more |= flag[k];
+            __syncthreads();
+            if (!more) break;
+        }
+        if (t == 0) status[2] = sweeps;
+        // eigenvalues lambda_j = v_j . (G v_j) = v_j . w_j + sigma
+        for (int j = wave; j < no; j += TL_ROT_T / 64) {
+            const double s = half_sum(lane < ne ? Vc[j][lane] * Wc[j][lane] : 0.0);
+            if (lane == 0) dd[j] = s + sigma;   // the occupied slots of dd now hold the new orbital energies
+        }
+        for (int e = t; e < n2o; e += TL_ROT_T) {
+            const int i = e / no, j = e - i * no;
+            Vo[e] = Vc[j][i];
+        }
+        __syncthreads();
+    }
+    QCDFT_STAMP(9);
+    // aufbau order: highest new occupied level against the lowest virtual diagonal (a necessary test only; the
+    // caller checks the converged state against a full diagonalisation, as scf.py does)
+    {
+        double eo = -INFINITY, dv = INFINITY;
+        if (t < no) eo = dd[t];
+        else if (t < n) dv = dd[t];
+        const double eomax = block_max(eo, red), dvmin = -block_max(-dv, red);
+        if (eomax > dvmin - 1e-3) {
+            if (t == 0) status[0] = 1;
+            return;
+        }
+    }
+    if (eig && t < n) eig[t] = dd[t];
+    // The new basis as ONE product U' = U W (the next launch, on the whole chip):
+    //   U_o' = (U_o + U_v K) c,   c = L^-T V                      ->  W[:, :no] = [c; K c]
+    //   U_v' = T (1 + K X K^T),   T = U_v - U_o K^T, X = -L^-T (1 + L)^-1  ->  W[:, no:] = [-(1 + M X) K^T; 1 + (K X) K^T]
+    double *Kc = Qm, *KX = Rm;   // Q and R are done with
+    wg_gemm(no, no, no, Lig, 1, no, Vo, no, 1, 1.0, 0.0, nullptr, 0, cd, no);          // c = L^-T V
+    wg_gemm(no, no, no, Lig, 1, no, L1g, no, 1, -1.0, 0.0, nullptr, 0, Xm, no);        // X = -L^-T (1 + L)^-1
+    __syncthreads();
+    wg_gemm(nv, no, no, Km, no, 1, cd, no, 1, 1.0, 0.0, nullptr, 0, Kc, no);
+    wg_gemm(nv, no, no, Km, no, 1, Xm, no, 1, 1.0, 0.0, nullptr, 0, KX, no);
+    wg_gemm(no, no, no, Pm, no, 1, Xm, no, 1, 1.0, 0.0, nullptr, 0, MX, no);           // M X
+    for (int e = t; e < n2o; e += TL_ROT_T) W[(size_t)(e / no) * n + e % no] = cd[e];
+    __syncthreads();
+    for (int e = t; e < n2o; e += TL_ROT_T) MX[e] += e / no == e % no ? 1.0 : 0.0;     // 1 + M X
+    for (int e = t; e < nk; e += TL_ROT_T) W[(size_t)(no + e / no) * n + e % no] = Kc[e];
+    __syncthreads();
+    wg_gemm(no, nv, no, MX, no, 1, Km, 1, no, -1.0, 0.0, nullptr, 0, W + no, n);                      // -(1 + M X) K^T
+    wg_gemm(nv, nv, no, KX, no, 1, Km, 1, no, 1.0, 0.0, nullptr, 0, W + (size_t)no * n + no, n);      // (K X) K^T ...
+    __syncthreads();
+    if (t < nv) W[(size_t)(no + t) * n + no + t] += 1.0;                                              // ... + 1
+    QCDFT_STAMP(10);
+#undef QCDFT_STAMP
+}
+
+// Row i of dm' = c' c'^T and of the energy traces; on success the new basis and orbitals replace the old ones.  The last
+// workgroup to finish adds the row partials in a fixed order and publishes them.
+__global__ __launch_bounds__(128) void k_tail_density(TailArgs a, int from_basis, unsigned long seq, const double *__restrict__ H,
+                                                      const double *__restrict__ J, const double *__restrict__ Kx,
+                                                      double *U, const double *Unew, double *dm, double *cocc,
+                                                      double *epart, int *status, const double *exc, double *out)
+{
+    __shared__ double ci[TL_MAXO], part[2][4];
+    __shared__ int last;
+    const int n = a.n, no = a.no, i = blockIdx.x, t = threadIdx.x;
+    const int st = from_basis ? 0 : status[0];
+    const double sc = 1.4142135623730951;           // dm = 2 C_occ C_occ^T (dft.py:182): cocc = sqrt(2) C_occ
+    const double *src = from_basis ? U : Unew;      // the caller's freshly diagonalised basis, or the rotated one
+    const int lds = n;
+    if (st == 0) {
+        if (t < TL_MAXO) ci[t] = t < no ? sc * src[(size_t)i * lds + t] : 0.0;
+        __syncthreads();
+        double p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0;
+        const int j = t;
+        if (j < n) {
+            double cj[TL_MAXO];
+#pragma unroll
+            for (int o = 0; o < TL_MAXO; ++o) cj[o] = o < no ? sc * src[(size_t)j * lds + o] : 0.0;
+            const double dold = dm[i * n + j], h = H[i * n + j], jj = J[i * n + j], kk = Kx ? Kx[i * n + j] : 0.0;
+            const double un = from_basis ? 0.0 : Unew[(size_t)i * n + j];
+            double dn = 0.0;
+#pragma unroll
+            for (int o = 0; o < TL_MAXO; ++o) dn = fma(ci[o], cj[o], dn);
+            const double diff = dn - dold;
+            p1 = dn * h; p2 = dn * jj; p3 = dn * kk; p4 = diff * diff;
+            dm[i * n + j] = dn;
+            if (!from_basis) U[(size_t)i * n + j] = un;   // nobody reads U in this mode: row i of the new basis replaces the old one
+        }
+        p1 = wave_sum(p1); p2 = wave_sum(p2); p3 = wave_sum(p3); p4 = wave_sum(p4);
+        if ((t & 63) == 0) { part[t >> 6][0] = p1; part[t >> 6][1] = p2; part[t >> 6][2] = p3; part[t >> 6][3] = p4; }
+        __syncthreads();
+        if (t < 4) epart[4 * i + t] = part[0][t] + part[1][t];
+        if (t < no) cocc[i * no + t] = ci[t];
+    }
+    __threadfence();
+    __syncthreads();
+    if (t == 0) last = atomicAdd(&status[3], 1) == n - 1;
+    __syncthreads();
+    if (!last) return;
+    // every other workgroup has finished (its stores are visible: fence before the ticket); a fixed summation tree
+    if (t < 64) {
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
+        if (st == 0)
+            for (int r = t; r < n; r += 64) { s1 += epart[4 * r]; s2 += epart[4 * r + 1]; s3 += epart[4 * r + 2]; s4 += epart[4 * r + 3]; }
+        s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
+        if (t == 0) {
+            out[0] = s1;                              // tr(dm' Hcore)
+            out[1] = 0.5 * s2;                        // dft.py:233
+            out[2] = Kx ? -0.25 * a.c_hf * s3 : 0.0;  // dft.py:234
+            out[3] = sqrt(s4);                        // |dm' - dm|
+            out[4] = (double)st;
+            out[5] = (double)status[1];
+            out[6] = (double)status[2];
+            if (exc) out[7] = *exc;                   // Exc of the sweep queued before this step (DFT_ComputeXC*Async)
+            status[3] = 0;
+            __threadfence_system();
+            ((volatile unsigned long *)out)[8] = seq;
+        }
+    }
+}
+
+// no rotation was asked for (no basis yet): the caller diagonalises F_ext
+__global__ void k_tail_need_exact(int *status)
+{
+    if (status[0] == 0) status[0] = 1;
+}
+
+__global__ void k_tail_begin(int *status)
+{
+    status[0] = 0; status[1] = 0; status[2] = 0;
+}
+
+void tail_error(TailDev *c, const char *what, hipError_t e)
+{
+    snprintf(c->err, sizeof c->err, "%s: %s", what, hipGetErrorString(e));
+    fprintf(stderr, "libdft: %s\n", c->err);
+}
+
+} // namespace
+
+extern "C" {
+
+void *DFT_ScfTailOpen(int nao, int nocc, unsigned long long d_hcore, unsigned long long d_overlap, unsigned long long d_basis,
+                      unsigned long long d_fock_out, unsigned long long d_mo_energy)
+{
+    if (nao < 2 || nao > TL_MAXN || nocc < 1 || nocc > TL_MAXO || nocc >= nao || !d_hcore || !d_overlap || !d_basis || !d_fock_out) return nullptr;
+    TailDev *c = new (std::nothrow) TailDev();
+    if (!c) return nullptr;
+    const size_t n = (size_t)nao, no = (size_t)nocc, nv = n - no, n2 = n * n;
+    c->n = nao; c->no = nocc;
+    c->H = (const double *)d_hcore; c->S = (const double *)d_overlap;
+    c->U = (double *)d_basis; c->Fx = (double *)d_fock_out; c->eig = (double *)d_mo_energy;
+    const size_t sizes[] = {TL_SPACE * n2, TL_SPACE * n2, TL_SPACE * TL_SPACE, n * no, n * no, n * TL_SPACE, n2, n2, n2,
+                            nv * no, nv * no, nv * no, no * no, 4 * n};
+    size_t total = 0;
+    for (size_t s : sizes) total += (s + 1) & ~(size_t)1;
+    if (hipMalloc((void **)&c->blob, total * sizeof(double) + 256) != hipSuccess ||
+        hipMemset(c->blob, 0, total * sizeof(double) + 256) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_out, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->h_out_dev, c->h_out, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->blob) (void)hipFree(c->blob);
+        if (c->h_out) (void)hipHostFree(c->h_out);
+        delete c;
+        return nullptr;
+    }
+    double **slots[] = {&c->Fb, &c->Eb, &c->Gb, &c->FC, &c->SC, &c->gpart, &c->FU, &c->A, &c->Unew, &c->Km, &c->Rm, &c->Qm, &c->Bm, &c->epart};
+    double *p = c->blob;
+    for (size_t i = 0; i < sizeof(sizes) / sizeof(sizes[0]); ++i) {
+        *slots[i] = p;
+        p += (sizes[i] + 1) & ~(size_t)1;
+    }
+    c->status = (int *)p;
+    memset(c->h_out, 0, 16 * sizeof(double));
+    // k_tail_rot: A in LDS during the fixed point (the completion's small matrices reuse its space), then K, B, Q, R as 160 KB allow
+    {
+        const size_t smalls = 5 * (size_t)TL_MAXO * TL_LD + 10 * no * no, budget = (160 * 1024 - 2048) / sizeof(double);
+        size_t off = (std::max(n2, smalls) + 1) & ~(size_t)1;
+        const size_t want[4] = {nv * no, no * no, nv * no, nv * no};
+        int *where[4] = {&c->lo.km, &c->lo.bm, &c->lo.qm, &c->lo.rm};
+        for (int k = 0; k < 4; ++k) {
+            const size_t sz = (want[k] + 1) & ~(size_t)1;
+            if (off + sz <= budget) { *where[k] = (int)off; off += sz; }
+        }
+        c->rot_lds = (unsigned)(off * sizeof(double));
+    }
+    if (hipFuncSetAttribute((const void *)k_tail_rot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->rot_lds) != hipSuccess) {
+        (void)hipGetLastError();
+        DFT_ScfTailClose(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void DFT_ScfTailClose(void *h)
+{
+    TailDev *c = (TailDev *)h;
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->blob) (void)hipFree(c->blob);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    delete c;
+}
+
+int DFT_ScfTailSetStream(void *h, unsigned long long hip_stream)
+{
+    TailDev *c = (TailDev *)h;
+    if (!c) return -1;
+    (void)hipStreamSynchronize(c->stream);
+    c->stream = (hipStream_t)hip_stream;
+    return 0;
+}
+
+const char *DFT_ScfTailLastError(void *h)
+{
+    TailDev *c = (TailDev *)h;
+    return c ? c->err : "null handle";
+}
+
+int DFT_ScfTailStep(void *h, int rotate, double c_hf, double tol, double canon_tol, int max_inner, int slot, int nhist, const int *hist,
+                    const double *coef, unsigned long long d_J, unsigned long long d_K, unsigned long long d_vraw,
+                    unsigned long long d_dm, unsigned long long d_cocc, unsigned long long d_exc)
+{
+    TailDev *c = (TailDev *)h;
+    if (!c) return -1;
+    c->err[0] = 0;
+    if (!d_J || !d_vraw || !d_dm || !d_cocc || nhist < 1 || nhist > TL_SPACE || slot < 0 || slot >= TL_SPACE || !hist) {
+        snprintf(c->err, sizeof c->err, "DFT_ScfTailStep: bad arguments");
+        return -1;
+    }
+    TailArgs a{};
+    a.n = c->n; a.no = c->no; a.slot = slot; a.nhist = nhist; a.have_coef = coef != nullptr; a.rotate = rotate != 0;
+    a.max_inner = max_inner > 0 ? max_inner : 60;
+    bool has_slot = false;
+    for (int s = 0; s < nhist; ++s) {
+        if (hist[s] < 0 || hist[s] >= TL_SPACE) { snprintf(c->err, sizeof c->err, "DFT_ScfTailStep: bad ring slot"); return -1; }
+        a.hist[s] = hist[s];
+        a.coef[s] = coef ? coef[s] : 0.0;
+        has_slot |= hist[s] == slot;
+    }
+    if (!has_slot) { snprintf(c->err, sizeof c->err, "DFT_ScfTailStep: the new slot is not in the history"); return -1; }
+    a.c_hf = c_hf; a.tol = tol; a.canon_tol = canon_tol > 0.0 ? canon_tol : 1e-3;
+    const int n = c->n;
+    const double *J = (const double *)d_J, *K = (const double *)d_K, *V = (const double *)d_vraw;
+    double *dm = (double *)d_dm, *cocc = (double *)d_cocc;
+    hipStream_t st = c->stream;
+    const unsigned long seq = ++c->seq;
+    const int nt = (n + 15) / 16;
+    hipLaunchKernelGGL(k_tail_fock, dim3(n), dim3(256), 0, st, a, c->H, c->S, J, K, V, cocc, c->Fb, c->FC, c->SC, c->status);
+    hipLaunchKernelGGL(k_tail_err, dim3(n), dim3(128), 0, st, a, c->FC, c->SC, c->Eb, c->gpart);
+    hipLaunchKernelGGL(k_tail_mix, dim3(n), dim3(128), 0, st, a, c->gpart, c->Gb, c->Fb, c->Fx, c->status);
+    if (a.rotate) {
+        hipLaunchKernelGGL(k_tail_gemm, dim3(nt * nt), dim3(256), 0, st, n, n, n, c->Fx, n, 1, c->U, n, 1, c->FU, n, c->status);   // F_ext U
+        hipLaunchKernelGGL(k_tail_gemm, dim3(nt * nt), dim3(256), 0, st, n, n, n, c->U, 1, n, c->FU, n, 1, c->A, n, c->status);    // U^T (F_ext U)
+        hipLaunchKernelGGL(k_tail_rot, dim3(1), dim3(TL_ROT_T), c->rot_lds, st, a, c->lo, c->A, c->U, c->Km, c->Rm, c->Qm, c->Bm, c->FU,
+                           c->eig, c->status, (long long *)(c->status + 8));
+        hipLaunchKernelGGL(k_tail_gemm, dim3(nt * nt), dim3(256), 0, st, n, n, n, c->U, n, 1, c->FU, n, 1, c->Unew, n, c->status);   // U' = U W
+    } else {
+        hipLaunchKernelGGL(k_tail_need_exact, dim3(1), dim3(1), 0, st, c->status);
+    }
+    hipLaunchKernelGGL(k_tail_density, dim3(n), dim3(128), 0, st, a, 0, seq, c->H, J, K, c->U, c->Unew, dm, cocc, c->epart,
+                       c->status, (const double *)d_exc, c->h_out_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { tail_error(c, "SCF tail launch", e); return -1; }
+    return 0;
+}
+
+int DFT_ScfTailFinish(void *h, double c_hf, unsigned long long d_J, unsigned long long d_K, unsigned long long d_dm, unsigned long long d_cocc)
+{
+    TailDev *c = (TailDev *)h;
+    if (!c) return -1;
+    c->err[0] = 0;
+    if (!d_J || !d_dm || !d_cocc) { snprintf(c->err, sizeof c->err, "DFT_ScfTailFinish: bad arguments"); return -1; }
+    TailArgs a{};
+    a.n = c->n; a.no = c->no; a.c_hf = c_hf;
+    const unsigned long seq = ++c->seq;
+    hipLaunchKernelGGL(k_tail_begin, dim3(1), dim3(1), 0, c->stream, c->status);
+    hipLaunchKernelGGL(k_tail_density, dim3(c->n), dim3(128), 0, c->stream, a, 1, seq, c->H, (const double *)d_J, (const double *)d_K,
+                       c->U, c->Unew, (double *)d_dm, (double *)d_cocc, c->epart, c->status, (const double *)nullptr, c->h_out_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { tail_error(c, "SCF tail launch", e); return -1; }
+    return 0;
+}
+
+int DFT_ScfTailWait(void *h, double *out)
+{
+    TailDev *c = (TailDev *)h;
+    if (!c || !out) return -1;
+    volatile unsigned long *word = (volatile unsigned long *)c->h_out + 8;
+    for (unsigned spins = 1; *word != c->seq; ++spins) {
+        if ((spins & 0xFFF) == 0) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipErrorNotReady) {
+                if (*word == c->seq) break;
+                if (q != hipSuccess) { tail_error(c, "SCF tail", q); return -1; }
+                // the stream is idle and the word has not arrived: one more look, then give up
+                if (hipStreamSynchronize(c->stream) == hipSuccess && *word == c->seq) break;
+                snprintf(c->err, sizeof c->err, "SCF tail: the result word never arrived");
+                return -1;
+            }
+        }
+        __builtin_ia32_pause();
+    }
+    for (int i = 0; i < 8; ++i) out[i] = ((volatile double *)c->h_out)[i];
+    return 0;
+}
+
+// Diagnostics: wall-clock stamps (100 MHz) of the last rotation kernel's phases (tools/tail_time.py)
+int DFT_ScfTailStamps(void *h, long long *host_out16)
+{
+    TailDev *c = (TailDev *)h;
+    if (!c || !host_out16) return -1;
+    if (hipStreamSynchronize(c->stream) != hipSuccess ||
+        hipMemcpy(host_out16, c->status + 8, 16 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return 0;
+}
+
+int DFT_ScfTailGram(void *h, double *host_out)
+{
+    TailDev *c = (TailDev *)h;
+    if (!c || !host_out) return -1;
+    const hipError_t e = hipMemcpyAsync(host_out, c->Gb, sizeof(double) * TL_SPACE * TL_SPACE, hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { tail_error(c, "copy Gram matrix", e); return -1; }
+    return 0;
+}
+
+} // extern "C"

@@ -111,7 +111,9 @@ def main(argv=None):
             st = eig_stats
             print(f"Eigensolver: {st['rotated']} cycles by occupied-subspace rotation ({st['inner_steps']} fixed-point steps), {st['exact']} by full diagonalisation")
         eig_dev = "occupied-subspace rotation, hipSOLVER eigh as fallback," if backend.occ_solver is not None else "hipSOLVER eigh"
-        print("Host part of the cycle: " + (f"device-resident (Fock build, DIIS, {eig_dev} in HBM)" if backend.device_resident
+        print("Host part of the cycle: " + ("device-resident: Fock build, DIIS, occupied-subspace rotation, density and energy traces as six launches of "
+                                            "libdft.so (DFT_ScfTailStep); full diagonalisations by host LAPACK" if getattr(backend, "tail", None) is not None else
+                                            f"device-resident (Fock build, DIIS, {eig_dev} in HBM)" if backend.device_resident
                                             else "host LAPACK eigh; [dm|cocc] up and [J|K|Vxc] down in one pinned transfer each"))
         print("-" * 80)
     else:
@@ -127,7 +129,7 @@ def main(argv=None):
               "E_tot": res.get("E_tot"), "E_one": res.get("E_one"), "E_coul": res.get("E_coul"), "E_xc": res.get("E_xc"),
               "E_ex_hf": res.get("E_ex_hf"), "E_nuc": float(inp.E_nuc), "total_time_s": res.get("total_time"),
               "xc_ms_avg": res.get("xc_ms_avg"), "xc_ms": res.get("xc_ms"), "jk_ms": res.get("jk_ms"), "iter_ms": res.get("iter_ms"),
-              "cycle_ms": res.get("cycle_ms"), "gpu_init_s": backend.init_time, "device_resident": bool(backend.device_resident), "ao": args.ao, "eigensolver": args.eigensolver,
+              "cycle_ms": res.get("cycle_ms"), "gpu_init_s": backend.init_time, "device_resident": bool(backend.device_resident), "loop": res.get("loop", "device" if backend.device_resident else "host"), "ao": args.ao, "eigensolver": args.eigensolver,
               "eigensolver_stats": eig_stats, "xc_occ": int(backend.xc_occ)}
     if other is not None:
         record["E_tot_other_quirks"] = other.get("E_tot"); record["other_quirks"] = 0 if args.quirks else 1

@@ -316,7 +316,8 @@ class HipBackend:
     rows of J (and, through the (i,k) view, its partial K); the all-reduce assembles them."""
 
     def __init__(self, inp, functional, lib_path=None, quirks=True, rank=0, world=1, device=None, group=None,
-                 device_resident=None, device_from=200, eigensolver="auto", ao_mode="resident", ao_chunk=0, xc_occ=True):
+                 device_resident=None, device_from=200, eigensolver="auto", ao_mode="resident", ao_chunk=0, xc_occ=True,
+                 fused_tail=None):
         import torch
         from .build import library_path
         from .grid_shard import ReplicaSync, ShardedFock, eri_row_bounds, shard_bounds, vector_bounds
@@ -396,6 +397,20 @@ class HipBackend:
             raise ValueError(f"eigensolver {eigensolver!r}: expected 'auto', 'rotate' or 'exact'")
         if eigensolver == "rotate" or (eigensolver == "auto" and nao >= 80):
             self.occ_solver = OccupiedRotation(inp.S, inp.nocc, self.dev if self.device_resident else None)
+        # The end of the cycle (Fock assembly, DIIS, rotation, density, energy traces) as six launches of libdft.so behind the
+        # cycle's J / K / Vxc (scf_tail.py, csrc/scf_tail.hip) where the rotation solver is in use and the sizes fit its
+        # single-workgroup rotation kernel: Benzene/def2-SVP 0.44 ms of host work per cycle -> ~0.1 ms of device work.
+        # None = auto (one rank, `device_resident` not forced off); the host and torch loops remain for everything else.
+        from . import scf_tail
+        self.tail = None
+        want_tail = (world == 1 and self.occ_solver is not None and device_resident is not False and ao_mode == "resident"
+                     and scf_tail.supported(nao, inp.nocc)) if fused_tail is None else bool(fused_tail)
+        if want_tail:
+            if not (world == 1 and scf_tail.supported(nao, inp.nocc)):
+                raise ValueError(f"fused_tail: one rank, nao <= {scf_tail.MAX_NAO} and nocc <= {scf_tail.MAX_NOCC} are needed")
+            if self.occ_solver is None or self.occ_solver.host is False:
+                self.occ_solver = OccupiedRotation(inp.S, inp.nocc, None)      # the counters the drivers report; the rotation itself runs in the kernel
+            self.tail = scf_tail.ScfTail(self.solver.lib, inp.Hcore, inp.S, inp.nocc, self.dev)
         if self.device_resident or self.diis_device is not None or self.eigh.on_device:
             # rocBLAS / hipSOLVER load their code objects and create their handles on first use (~0.1-0.3 s in all):
             # done here, on operands of the run's own shapes, so that it is booked as initialisation -- where the
@@ -497,6 +512,8 @@ def run_scf(inp, backend, functional, max_cycle=200, conv_e=1e-8, conv_dm=1e-6, 
     # functions one thread is fastest for everything left on the host (dsyevd at n = 114: 0.67 ms on one
     # thread, 0.87 on 16), above it the pool gets the CPU share
     with blas_threads(1 if inp.S.shape[0] < 400 else None):
+        if getattr(backend, "tail", None) is not None:
+            return _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log)
         if getattr(backend, "device_resident", False):
             return _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log)
         return _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log)
@@ -550,6 +567,8 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     E_old, xc_times, jk_times, it_times, t_start = 0.0, [], [], [], time.time()
     res = {"converged": False}
     want_k = functional == "B3LYP"
+    import os
+    prof = [] if os.environ.get("QCDFT_SCF_PROFILE") else None      # per-part times of the host side of a cycle
     for cycle in range(max_cycle):
         t_it = time.time()
         if hasattr(backend, "fock_parts"):
@@ -563,15 +582,22 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         jk_times.append(t_jk); xc_times.append(t_xc)
         dm_new, cocc_new, scal = np.empty_like(dm), np.empty_like(cocc), np.zeros(4)
         if root or sync is None:   # rank 0 is authoritative: DIIS + eigh run once, replicas receive the result
+            tp = [time.time()]
             Vxc = 0.5 * (Vraw + Vraw.T)                                                # dft.py:212
             F = Hcore + J + Vxc - (c_hf * 0.5 * K if K is not None else 0.0)           # dft.py:221,223
+            tp.append(time.time())
             F = diis.update(S, dm, F, cocc=cocc)
+            tp.append(time.time())
             e, C = solve(F)
+            tp.append(time.time())
             cocc_new = np.ascontiguousarray(np.sqrt(2.0) * C)
             dm_new = cocc_new @ cocc_new.T
             scal = np.array([np.sum(dm_new * Hcore), 0.5 * np.sum(dm_new * J),
                              -0.25 * c_hf * np.sum(dm_new * K) if K is not None else 0.0,
                              np.linalg.norm(dm_new - dm)])
+            tp.append(time.time())
+            if prof is not None:
+                prof.append([1e3 * (tp[0] - t_it - t_jk - t_xc)] + [1e3 * (b - a) for a, b in zip(tp, tp[1:])])
         if sync:
             sync.broadcast_numpy([dm_new, cocc_new, scal])
         E_one, E_coul, E_ex, ddm = (float(x) for x in scal)
@@ -606,6 +632,11 @@ def _run_scf(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
             if log:
                 log("     converged occupied space is not the aufbau one: continuing with eigh(F, S) every cycle")
         dm, cocc, E_old = dm_new, cocc_new, E_tot
+    if prof:
+        med = np.median(np.array(prof[1:] if len(prof) > 1 else prof), axis=0)
+        res["host_parts_ms"] = dict(zip(("transfers", "fock", "diis", "eigen", "density_energies"), (float(x) for x in med)))
+        if log:
+            log("host parts (median ms per cycle): " + ", ".join(f"{k} {v:.3f}" for k, v in res["host_parts_ms"].items()))
     return _finish(res, t_start, xc_times, jk_times, it_times)
 
 
@@ -716,4 +747,96 @@ def _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         res["device_parts_ms"] = dict(zip(("fock", "diis", "eigen", "density_energies"), (float(x) for x in med)))
         if log:
             log("device-resident parts (median ms per cycle): " + ", ".join(f"{k} {v:.3f}" for k, v in res["device_parts_ms"].items()))
+    return _finish(res, t_start, xc_times, jk_times, it_times)
+
+
+def _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
+    """The loop with its host part on the device (scf_tail.ScfTail): per cycle the J / K and XC kernels, then six launches for
+    dft.py:212-236, then ONE wait on host-mapped memory for the four energy / convergence scalars.  The few full
+    diagonalisations of a run (first cycle, refused rotations, the final aufbau check) are LAPACK calls on the host,
+    as in the other two loops at this size."""
+    t = backend.torch
+    tail, rot_stats = backend.tail, backend.occ_solver.stats
+    functional = functional.upper()
+    c_hf = 0.2 if functional == "B3LYP" else 0.0
+    want_k = functional == "B3LYP"
+    nocc, Xh = inp.nocc, backend.eigh.Xh
+    sqrt2 = float(np.sqrt(2.0))
+
+    def diagonalise_into_basis(F):                                                     # dft.py:181,227
+        e_, Cp = eigh(Xh.T @ F @ Xh, driver="evd")
+        U = Xh @ Cp
+        tail.basis.copy_(t.from_numpy(np.ascontiguousarray(U)))
+        rot_stats["exact"] += 1
+        return e_, U
+
+    tail.reset()
+    e, U = diagonalise_into_basis(inp.Hcore)
+    cocc0 = np.ascontiguousarray(sqrt2 * U[:, :nocc])
+    backend.d_cocc.copy_(t.from_numpy(cocc0)); backend.d_dm.copy_(t.from_numpy(cocc0 @ cocc0.T))   # dft.py:182
+    _log_header(log)
+    E_old, xc_times, jk_times, it_times, t_start = 0.0, [], [], [], time.time()
+    res = {"converged": False}
+    rotate, last_ddm = True, None
+    d_K = backend.d_K if want_k else None
+    d_exc = t.zeros(1, dtype=t.float64, device=backend.dev)
+    marks = []                                                                         # (start, J/K done, XC done) events per cycle
+    sol = backend.solver
+    for cycle in range(max_cycle):
+        t_it = time.time()
+        # the whole cycle is queued without a host wait in between: J/K, the sweep (Exc stays on the device), the tail
+        ev = [t.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        backend._jk_device(want_k)
+        ev[1].record()
+        if backend.xc_occ:
+            sol.compute_xc_occ_async(backend.ngrid, backend.nao, nocc, backend.d_cocc, backend.d_ao, backend.d_w, backend.d_v, d_exc,
+                                     backend.d_gr, backend.d_dm)
+        else:
+            sol.compute_xc_async(backend.ngrid, backend.nao, backend.d_dm, backend.d_ao, backend.d_w, backend.d_v, d_exc, backend.d_gr)
+        ev[2].record()
+        marks.append(ev)
+        tol = 1e-10 if last_ddm is None else min(max(1e-10, 1e-3 * last_ddm), 1e-5)    # as OccupiedRotation.occupied(accuracy)
+        tail.step(rotate, c_hf, tol, backend.d_J, d_K, backend.d_v, backend.d_dm, backend.d_cocc, d_exc=d_exc)
+        E_one, E_coul, E_ex, ddm, status, steps, _, E_xc = tail.wait()
+        if status == 2:                                                                # singular Pulay system: least squares on the host
+            tail.step(rotate, c_hf, tol, backend.d_J, d_K, backend.d_v, backend.d_dm, backend.d_cocc,
+                      coef=tail.pulay_coefficients_on_host(), repeat=True)
+            E_one, E_coul, E_ex, ddm, status, steps, _, _ = tail.wait()
+        if status == 1:                                                                # no rotation (asked for, or possible): full solve
+            e, _ = diagonalise_into_basis(tail.fock.cpu().numpy())
+            tail.finish(c_hf, backend.d_J, d_K, backend.d_dm, backend.d_cocc)
+            E_one, E_coul, E_ex, ddm, status, _, _, _ = tail.wait()
+        else:
+            rot_stats["rotated"] += 1; rot_stats["inner_steps"] += steps
+        if status != 0:
+            raise RuntimeError(f"SCF tail: status {status}")
+        last_ddm = ddm
+        E_tot = E_one + E_coul + E_xc + E_ex + inp.E_nuc
+        dE = E_tot - E_old
+        it_times.append(time.time() - t_it)
+        if log:
+            log(f"{cycle + 1:4d} {E_tot:18.8f} {dE:15.6e} {ddm:15.6e} {E_ex:12.6f}")
+        res.update(E_tot=E_tot, E_one=E_one, E_coul=E_coul, E_xc=E_xc, E_ex_hf=E_ex, cycles=cycle + 1)
+        if abs(dE) < conv_e and ddm < conv_dm:
+            ok = True
+            if rotate:                                                                 # as in _run_scf: the followed space against eigh(F, S)
+                e_x, Cp = eigh(Xh.T @ tail.fock.cpu().numpy() @ Xh, driver="evd")
+                C_x = Xh @ Cp
+                ok = bool(np.linalg.norm(2.0 * C_x[:, :nocc] @ C_x[:, :nocc].T - backend.d_dm.cpu().numpy()) < 1e-4)
+                if ok:
+                    e = e_x
+            if ok:
+                res["converged"] = True
+                break
+            rotate = False
+            tail.reset()
+            if log:
+                log("     converged occupied space is not the aufbau one: continuing with eigh(F, S) every cycle")
+        E_old = E_tot
+    res["dm"] = backend.d_dm.cpu().numpy()
+    res["mo_energy"] = np.asarray(e)
+    res["loop"] = "fused"
+    for ev in marks:                                                                   # device-side durations: nothing waited in between
+        jk_times.append(1e-3 * ev[0].elapsed_time(ev[1])); xc_times.append(1e-3 * ev[1].elapsed_time(ev[2]))
     return _finish(res, t_start, xc_times, jk_times, it_times)

@@ -132,3 +132,54 @@ def test_occ_call_without_orbitals_is_an_error(dev):
     d = torch.zeros((16, 16), dtype=torch.float64, device=dev)
     with pytest.raises(RuntimeError):
         s.compute_xc_occ(16, 16, 4, None, d, d[0], d, torch.zeros((3, 16, 16), dtype=torch.float64, device=dev))
+
+
+def test_recorded_graph_replay_is_bit_identical_and_follows_new_inputs():
+    """Option "graph": the third and later calls with the same pointers are one hipGraphLaunch; results are those of the
+    plain launches bit for bit, new values behind the same pointers are picked up, a new pointer takes plain launches again."""
+    import torch
+    import quantum_compute_dft_amd as q
+    dev = torch.device("cuda:0")
+    ngrid, nao, nocc = 5000, 24, 5
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    ao = 0.4 * torch.randn((ngrid, nao), dtype=torch.float64, device=dev, generator=g)
+    gr = 0.3 * torch.randn((3, ngrid, nao), dtype=torch.float64, device=dev, generator=g)
+    w = 0.05 * torch.rand((ngrid,), dtype=torch.float64, device=dev, generator=g)
+    c = torch.randn((nao, nocc), dtype=torch.float64, device=dev, generator=g)
+    dm = (c @ c.T).contiguous()
+    for xc in ("LDA", "GGA", "B3LYP"):
+        s = q.DFTSolverWrapper(q.library_path(), xc)
+        grad = None if xc == "LDA" else gr
+        ref = {}
+        s.set_option("graph", 0)
+        for scale in (1.0, 0.5):
+            d = (scale * dm).contiguous(); v = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
+            ref[scale] = (s.compute_xc(ngrid, nao, d, ao, w, v, grad), v.clone())
+        for mode in (1, -1):
+            s.set_option("graph", mode)
+            d = dm.clone(); v = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
+            for rep in range(4):                        # plain, recorded, replayed, replayed
+                v.zero_()
+                e = s.compute_xc(ngrid, nao, d, ao, w, v, grad)
+                assert e == ref[1.0][0] and torch.equal(v, ref[1.0][1]), (xc, mode, rep)
+            d.mul_(0.5)                                 # same pointers, new density: the replay reads it
+            e = s.compute_xc(ngrid, nao, d, ao, w, v, grad)
+            assert e == ref[0.5][0] and torch.equal(v, ref[0.5][1]), (xc, mode)
+            v2 = torch.zeros_like(v)                    # another output pointer: a new key
+            e = s.compute_xc(ngrid, nao, d, ao, w, v2, grad)
+            assert e == ref[0.5][0] and torch.equal(v2, ref[0.5][1]), (xc, mode)
+            # a larger call in between grows the workspace: the recorded graphs are dropped, not replayed stale
+            big = torch.cat([ao, ao, ao]); bw = torch.cat([w, w, w]); bg = None if grad is None else torch.cat([gr, gr, gr], dim=1).contiguous()
+            vb = torch.zeros_like(v)
+            eb = s.compute_xc(3 * ngrid, nao, d, big, bw, vb, bg)
+            assert abs(eb - 3 * ref[0.5][0]) <= 1e-11 * abs(eb)
+            for rep in range(3):
+                v.zero_()
+                e = s.compute_xc(ngrid, nao, d, ao, w, v, grad)
+                assert e == ref[0.5][0] and torch.equal(v, ref[0.5][1]), (xc, mode, "after growth", rep)
+        cs = (np.sqrt(0.5) * c).contiguous()            # the occupied entry through the same mechanism
+        s.set_option("graph", 1)
+        for rep in range(3):
+            v.zero_()
+            e = s.compute_xc_occ(ngrid, nao, nocc, cs, ao, w, v, grad, d)
+            assert abs(e - ref[0.5][0]) <= 1e-12 * abs(e) and (v - ref[0.5][1]).abs().max() <= 1e-11 * ref[0.5][1].abs().max()

@@ -1,0 +1,175 @@
+"""The device-resident end of an SCF cycle (csrc/scf_tail.hip, DFT_ScfTail*) against the host loop's own numpy classes
+(scf.CDIIS, scf.OccupiedRotation) on the same inputs, and the fused loop against the host loop on a real molecule."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pytestmark = pytest.mark.gpu
+
+import quantum_compute_dft_amd as q  # noqa: E402
+from quantum_compute_dft_amd import scf, scf_tail  # noqa: E402
+
+
+def _problem(n, no, seed, c_hf):
+    """A Fock-like problem with a gap: S near 1, H with a split spectrum, small symmetric J / K and a non-symmetric Vxc."""
+    rng = np.random.default_rng(seed)
+    B = 0.1 * rng.standard_normal((n, n))
+    S = np.eye(n) + 0.5 * (B + B.T) / np.sqrt(n)
+    s, V = np.linalg.eigh(S)
+    X = V / np.sqrt(s)
+    lev = np.concatenate([np.sort(rng.uniform(-10.0, -0.5, no)), np.sort(rng.uniform(0.2, 4.0, n - no))])
+    Q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    Xi = np.linalg.inv(X)
+    H = Xi.T @ (Q * lev) @ Q.T @ Xi          # X^T H X has the spectrum `lev`
+    H = 0.5 * (H + H.T)
+    sym = lambda a: 0.5 * (a + a.T)
+    mats = [(0.02 * sym(rng.standard_normal((n, n))), 0.02 * sym(rng.standard_normal((n, n))), 0.02 * rng.standard_normal((n, n))) for _ in range(12)]
+    return S, X, H, mats
+
+
+def _host_cycle(S, H, J, K, V, c_hf, dm, cocc, diis, rot, tol):
+    """dft.py:212-236 as scf._run_scf does it."""
+    F = H + J + 0.5 * (V + V.T) - (0.5 * c_hf * K if c_hf else 0.0)
+    F = diis.update(S, dm, F, cocc=cocc)
+    e, C = rot.occupied(F, tol)
+    cn = np.sqrt(2.0) * np.asarray(C)
+    dn = cn @ cn.T
+    return F, dn, cn, (np.sum(dn * H), 0.5 * np.sum(dn * J), -0.25 * c_hf * np.sum(dn * K) if c_hf else 0.0, np.linalg.norm(dn - dm))
+
+
+@pytest.mark.parametrize("n,no,c_hf", [(30, 7, 0.0), (114, 21, 0.0), (114, 21, 0.2), (128, 32, 0.2), (17, 1, 0.0), (45, 30, 0.2)])
+def test_tail_steps_match_the_host_classes(n, no, c_hf):
+    import torch
+    dev = torch.device("cuda:0")
+    S, X, H, mats = _problem(n, no, 100 + n + no, c_hf)
+    lib = q.load_library(q.library_path())
+    tail = scf_tail.ScfTail(lib, H, S, no, dev)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    # cycle 0: the full diagonalisation of H (both sides start from the same basis)
+    from scipy.linalg import eigh
+    e0, Cp = eigh(X.T @ H @ X, driver="evd")
+    U0 = X @ Cp
+    rot = scf.OccupiedRotation(S, no, None)
+    rot.U = U0.copy()
+    diis = scf.CDIIS()
+    tail.basis.copy_(t(U0))
+    cocc = np.sqrt(2.0) * U0[:, :no]
+    dm = cocc @ cocc.T
+    d_dm, d_cocc = t(dm), t(cocc)
+    d_exc = torch.zeros(1, dtype=torch.float64, device=dev)
+    for cyc, (J, K, V) in enumerate(mats):
+        tol = 1e-10
+        d_exc.fill_(-1.25 - cyc)
+        Fh, dn, cn, (e1, e2, e3, dd) = _host_cycle(S, H, J, K, V, c_hf, dm, cocc, diis, rot, tol)
+        d_J, d_K, d_V = t(J), (t(K) if c_hf else None), t(V)
+        tail.step(True, c_hf, tol, d_J, d_K, d_V, d_dm, d_cocc, canon_tol=1e-6, d_exc=d_exc)
+        o = tail.wait()
+        assert o[4] == scf_tail.STATUS_DONE, (cyc, o)
+        assert o[7] == -1.25 - cyc                                                         # the sweep's Exc travels with the step's scalars
+        scale = np.abs(Fh).max()
+        assert np.abs(tail.fock.cpu().numpy() - Fh).max() <= 1e-11 * scale, cyc           # Fock assembly + DIIS
+        got_dm = d_dm.cpu().numpy()
+        assert np.abs(got_dm - dn).max() <= 2e-9, (cyc, np.abs(got_dm - dn).max())         # the rotated occupied space (fixed point to 1e-10)
+        c_got = d_cocc.cpu().numpy()
+        assert np.abs(c_got @ c_got.T - got_dm).max() <= 1e-12                            # dm = cocc cocc^T
+        Ub = tail.basis.cpu().numpy()
+        assert np.abs(Ub.T @ S @ Ub - np.eye(n)).max() <= 1e-11                           # the basis stays S-orthonormal
+        assert np.abs(np.sqrt(2.0) * Ub[:, :no] - c_got).max() <= 1e-13
+        Aoo = Ub[:, :no].T @ Fh @ Ub[:, :no]
+        assert np.abs(Aoo - np.diag(np.diag(Aoo))).max() <= 1e-7                          # ... and canonical in the occupied block
+        assert np.abs(np.diag(Aoo) - tail.mo_energy.cpu().numpy()[:no]).max() <= 1e-9
+        for got, ref in zip(o[:4], (e1, e2, e3, dd)):
+            assert abs(got - ref) <= 1e-9 * max(1.0, abs(ref)), (cyc, o, (e1, e2, e3, dd))
+        assert o[5] >= 1
+        # both sides continue from THEIR OWN state (they agree to ~1e-10: the trajectories stay together)
+        dm, cocc = dn, cn
+    tail.close()
+
+
+def test_status_paths_diis_only_finish_and_singular_system():
+    import torch
+    from scipy.linalg import eigh
+    dev = torch.device("cuda:0")
+    n, no, c_hf = 40, 9, 0.2
+    S, X, H, mats = _problem(n, no, 5, c_hf)
+    lib = q.load_library(q.library_path())
+    tail = scf_tail.ScfTail(lib, H, S, no, dev)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    e0, Cp = eigh(X.T @ H @ X, driver="evd")
+    U0 = X @ Cp
+    cocc = np.sqrt(2.0) * U0[:, :no]
+    dm = cocc @ cocc.T
+    d_dm, d_cocc = t(dm), t(cocc)
+    J, K, V = mats[0]
+    d_J, d_K, d_V = t(J), t(K), t(V)
+    # DIIS only: status 1, the Fock matrix is there, nothing else changed
+    tail.step(False, c_hf, 1e-10, d_J, d_K, d_V, d_dm, d_cocc)
+    o = tail.wait()
+    assert o[4] == scf_tail.STATUS_DIAGONALISE
+    F = H + J + 0.5 * (V + V.T) - 0.5 * c_hf * K
+    assert np.abs(tail.fock.cpu().numpy() - F).max() <= 1e-13 * np.abs(F).max()
+    assert np.array_equal(d_dm.cpu().numpy(), dm) and np.array_equal(d_cocc.cpu().numpy(), cocc)
+    # the caller diagonalises and finishes
+    e1, Cp1 = eigh(X.T @ F @ X, driver="evd")
+    U1 = X @ Cp1
+    tail.basis.copy_(t(U1))
+    tail.finish(c_hf, d_J, d_K, d_dm, d_cocc)
+    o = tail.wait()
+    cn = np.sqrt(2.0) * U1[:, :no]
+    dn = cn @ cn.T
+    assert o[4] == scf_tail.STATUS_DONE
+    assert np.abs(d_dm.cpu().numpy() - dn).max() <= 1e-13 and np.abs(d_cocc.cpu().numpy() - cn).max() <= 1e-15
+    for got, ref in zip(o[:4], (np.sum(dn * H), 0.5 * np.sum(dn * J), -0.25 * c_hf * np.sum(dn * K), np.linalg.norm(dn - dm))):
+        assert abs(got - ref) <= 1e-11 * max(1.0, abs(ref))
+    # a rotation that must be refused: a Fock matrix far from the basis (first-order step above 0.5)
+    Jbig = J + 3.0 * (lambda a: a + a.T)(np.random.default_rng(1).standard_normal((n, n)))
+    before = tail.basis.clone()
+    tail.reset()                                   # no history: DIIS would otherwise extrapolate the outlier away
+    tail.step(True, c_hf, 1e-10, t(Jbig), d_K, d_V, d_dm, d_cocc)
+    o = tail.wait()
+    assert o[4] == scf_tail.STATUS_DIAGONALISE and torch.equal(tail.basis, before)
+    # the same (F, e) pair twice in the ring: a singular Pulay system -> status 2 -> coefficients from the host
+    tail.reset()
+    d_dm2, d_cocc2 = t(dn), t(cn)
+    tail.step(False, c_hf, 1e-10, d_J, d_K, d_V, d_dm2, d_cocc2)
+    assert tail.wait()[4] == scf_tail.STATUS_DIAGONALISE
+    tail.step(False, c_hf, 1e-10, d_J, d_K, d_V, d_dm2, d_cocc2)
+    o = tail.wait()
+    assert o[4] == scf_tail.STATUS_SINGULAR, o
+    cf = tail.pulay_coefficients_on_host()
+    assert abs(cf.sum() - 1.0) <= 1e-12
+    tail.step(False, c_hf, 1e-10, d_J, d_K, d_V, d_dm2, d_cocc2, coef=cf, repeat=True)
+    o = tail.wait()
+    assert o[4] == scf_tail.STATUS_DIAGONALISE
+    assert np.abs(tail.fock.cpu().numpy() - F).max() <= 1e-12 * np.abs(F).max()      # any weights summing to 1 of two equal matrices
+    tail.close()
+    assert scf_tail.supported(114, 21) and not scf_tail.supported(246, 47)
+
+
+@pytest.mark.parametrize("functional,eri", [("GGA", "dense"), ("B3LYP", "cholesky")])
+def test_fused_loop_matches_the_host_loop_on_benzene(functional, eri):
+    """Same molecule, same thresholds (dft.py:243): the loop with its host part on the device against the host loop."""
+    import torch
+    from quantum_compute_dft_amd import inputs
+    dev = torch.device("cuda:0")
+    inp = inputs.build("Benzene", "def2-svp", 3, device=dev, verbose=False, eri_mode=eri, chol_tol=1e-8)
+    host = scf.HipBackend(inp, functional, device=dev, device_resident=False)
+    assert host.tail is None
+    r_host = scf.run_scf(inp, host, functional, log=None)
+    fused = scf.HipBackend(inp, functional, device=dev)
+    assert fused.tail is not None
+    r_fused = scf.run_scf(inp, fused, functional, log=None)
+    assert r_host["converged"] and r_fused["converged"] and r_fused["loop"] == "fused"
+    assert abs(r_host["E_tot"] - r_fused["E_tot"]) <= 2e-8, (r_host["E_tot"], r_fused["E_tot"])
+    assert abs(r_host["cycles"] - r_fused["cycles"]) <= 1
+    assert np.abs(r_host["dm"] - r_fused["dm"]).max() <= 1e-5
+    assert np.abs(np.asarray(r_host["mo_energy"]) - np.asarray(r_fused["mo_energy"])).max() <= 1e-5
+    st = fused.occ_solver.stats
+    assert st["rotated"] >= r_fused["cycles"] // 2 and st["exact"] >= 1
+    # a second run on the same backend starts afresh
+    fused.occ_solver.reset()
+    r2 = scf.run_scf(inp, fused, functional, log=None)
+    assert r2["converged"] and abs(r2["E_tot"] - r_fused["E_tot"]) <= 1e-9 and r2["cycles"] == r_fused["cycles"]
