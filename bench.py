@@ -364,12 +364,15 @@ def scf_real_leg(lib_path, dev, molecule="Benzene", functional="GGA", basis_name
     for name, ii in (("dense_eri", inp), ("factorised_j", inp_cd)):
         # auto / exact: the XC sweep through DFT_ComputeXCOcc (the loop holds cocc); abi_xc: eigensolver auto with the
         # reference ABI's DFT_ComputeXC (full density matrix) beside it
-        for eig, occ in (("auto", True), ("exact", True), ("abi_xc", False)):
-            be = scf.HipBackend(ii, functional, lib_path, device=dev, eigensolver="auto" if eig == "abi_xc" else eig, xc_occ=occ)
+        # host_loop: rounds 2-3's loop (Fock assembly, DIIS, rotation in numpy on the host, one pinned transfer each way)
+        for eig, occ in (("auto", True), ("exact", True), ("abi_xc", False), ("host_loop", True)):
+            be = scf.HipBackend(ii, functional, lib_path, device=dev, eigensolver="exact" if eig == "exact" else "auto", xc_occ=occ,
+                                device_resident=False if eig == "host_loop" else None)
             r = scf.run_scf(ii, be, functional, log=None)
             out[f"{name}_{eig}"] = {"ms_per_cycle": r["iter_ms"], "xc_ms": r["xc_ms"], "jk_ms": r["jk_ms"], "cycles": r["cycles"],
                                     "converged": bool(r["converged"]), "E_tot": r["E_tot"], "total_ms": 1e3 * r["total_time"],
                                     "xc_entry_point": "DFT_ComputeXCOcc" if occ else "DFT_ComputeXC",
+                                    "loop": r.get("loop", "host"),
                                     "eigensolver": dict(be.occ_solver.stats) if be.occ_solver is not None else "eigh(F, S) every cycle"}
             del be
     del inp, inp_cd
@@ -829,9 +832,13 @@ def main():
                                        ("scf_iteration_factorised_j", "factorised_j_auto", "factorised J (Cholesky vectors, 1e-8)")):
                     r = real[src]
                     put(key, {"ms": r["ms_per_cycle"], "workload": real["workload"] + "; " + what, "statistic": real["statistic"],
-                                 "parts_ms": {"xc": r["xc_ms"], "jk": r["jk_ms"], "host_eigen_diis_fock_transfers": r["ms_per_cycle"] - r["xc_ms"] - r["jk_ms"]},
+                                 "loop": ("fused: Fock assembly, DIIS, occupied-subspace rotation, density and energy traces as kernels of libdft.so behind the "
+                                          "cycle's J/K and sweep (DFT_ScfTailStep), one host wait per cycle; xc / jk are device-side durations (events)"
+                                          if r.get("loop") == "fused" else r.get("loop")),
+                                 "parts_ms": {"xc": r["xc_ms"], "jk": r["jk_ms"], "fock_diis_eigen_density_and_waits": r["ms_per_cycle"] - r["xc_ms"] - r["jk_ms"]},
                                  "cycles": r["cycles"], "converged": r["converged"], "E_tot": r["E_tot"], "eigensolver": r["eigensolver"],
                                  "eigh_every_cycle_ms": real[src.replace("_auto", "_exact")]["ms_per_cycle"],
+                                 "host_loop": real.get(src.replace("_auto", "_host_loop")),
                                  "xc_entry_point": "DFT_ComputeXCOcc (the driver holds cocc; scf.HipBackend default)",
                                  "abi_xc_entry": real.get(src.replace("_auto", "_abi_xc"))})
                 # the same loop body with synthetic operands and eigh(F, S) EVERY cycle (round 1's legs, kept for comparison)

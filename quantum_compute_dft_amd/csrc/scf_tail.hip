@@ -311,12 +311,27 @@ __global__ __launch_bounds__(256) void k_tail_gemm(int M, int N, int Kd, const d
 }
 
 // C (M x N, ldc) = alpha sum_k A(i, k) B(k, j) + beta D(i, j) by the whole workgroup on the fp64 matrix cores, one 16 x 16 tile
-// per wave at a time; A(i, k) = a[i ars + k acs], B(k, j) = b[k brs + j bcs] -- transposes are strides; operands in LDS or
-// memory (generic pointers), eight contraction steps' worth loaded ahead of their MFMAs.  The caller puts a barrier
-// between dependent products.
-__device__ void wg_gemm(int M, int N, int Kd, const double *a, int ars, int acs, const double *b, int brs, int bcs,
-                        double alpha, double beta, const double *d, int ldd, double *c, int ldc)
+// per wave at a time; A(i, k) = a[i ars + k acs], B(k, j) = b[k brs + j bcs] -- transposes are strides.  LDS = true: every
+// operand and the result live in the workgroup's LDS (ds_read / ds_write with 32-bit addresses; through generic pointers
+// the same loads are flat instructions with 64-bit address arithmetic, measured 2-3x slower here); false: anywhere.
+// Eight contraction steps' worth of operands are loaded ahead of their MFMAs, which alternate between two accumulators
+// (a dependent fp64 MFMA waits out the 16 passes of the one before).  The caller puts a barrier between dependent products.
+template <bool LDS> struct TailPtr;
+template <> struct TailPtr<false> {
+    typedef const double *ro;
+    typedef double *rw;
+};
+template <> struct TailPtr<true> {
+    typedef const __attribute__((address_space(3))) double *ro;
+    typedef __attribute__((address_space(3))) double *rw;
+};
+
+template <bool LDS>
+__device__ __forceinline__ void wg_gemm_t(int M, int N, int Kd, const double *a_, int ars, int acs, const double *b_, int brs, int bcs,
+                                          double alpha, double beta, const double *d_, int ldd, double *c_, int ldc)
 {
+    typename TailPtr<LDS>::ro a = (typename TailPtr<LDS>::ro)a_, b = (typename TailPtr<LDS>::ro)b_, d = (typename TailPtr<LDS>::ro)d_;
+    typename TailPtr<LDS>::rw c = (typename TailPtr<LDS>::rw)c_;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int mt = (M + 15) >> 4, nt = (N + 15) >> 4;
     const int li = lane & 15, kq = lane >> 4;
@@ -324,30 +339,43 @@ __device__ void wg_gemm(int M, int N, int Kd, const double *a, int ars, int acs,
         const int i0 = (tile / nt) << 4, j0 = (tile % nt) << 4;
         const int ia = i0 + li, jb = j0 + li;
         const bool aok = ia < M, bok = jb < N;
-        const double *ap = a + (size_t)(aok ? ia : 0) * ars, *bp = b + (size_t)(bok ? jb : 0) * bcs;
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const int aoff = (aok ? ia : 0) * ars, boff = (bok ? jb : 0) * bcs;
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
         for (int k0 = 0; k0 < Kd; k0 += 32) {
             double av[8], bv[8];
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int k = k0 + 4 * s + kq;
                 const bool kok = k < Kd;
-                av[s] = aok && kok ? ap[(size_t)k * acs] : 0.0;
-                bv[s] = bok && kok ? bp[(size_t)k * brs] : 0.0;
+                av[s] = aok && kok ? a[aoff + k * acs] : 0.0;
+                bv[s] = bok && kok ? b[boff + k * brs] : 0.0;
             }
 #pragma unroll
-            for (int s = 0; s < 8; ++s) acc = mfma_f64(av[s], bv[s], acc);
+            for (int s = 0; s < 8; s += 2) {
+                acc0 = mfma_f64(av[s], bv[s], acc0);
+                acc1 = mfma_f64(av[s + 1], bv[s + 1], acc1);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = i0 + kq + 4 * r, col = j0 + li;
             if (row < M && col < N) {
-                double v = alpha * acc[r];
-                if (beta != 0.0) v += beta * d[(size_t)row * ldd + col];
-                c[(size_t)row * ldc + col] = v;
+                double v = alpha * (acc0[r] + acc1[r]);
+                if (beta != 0.0) v += beta * d[row * ldd + col];
+                c[row * ldc + col] = v;
             }
         }
     }
+}
+__device__ void wg_gemm(int M, int N, int Kd, const double *a, int ars, int acs, const double *b, int brs, int bcs,
+                        double alpha, double beta, const double *d, int ldd, double *c, int ldc)
+{
+    wg_gemm_t<false>(M, N, Kd, a, ars, acs, b, brs, bcs, alpha, beta, d, ldd, c, ldc);
+}
+__device__ void wg_gemm_lds(int M, int N, int Kd, const double *a, int ars, int acs, const double *b, int brs, int bcs,
+                            double alpha, double beta, const double *d, int ldd, double *c, int ldc)
+{
+    wg_gemm_t<true>(M, N, Kd, a, ars, acs, b, brs, bcs, alpha, beta, d, ldd, c, ldc);
 }
 
 __device__ double block_max(double v, double *scratch)
@@ -443,6 +471,7 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
     const int n = a.n, no = a.no, nv = n - no, t = threadIdx.x, nk = nv * no;
     if (status[0] != 0) return;   // the DIIS system was singular: nothing to rotate
     QCDFT_STAMP(0);
+    if (threadIdx.x == 0) stamps[11] = (long long)clock64();
     double *As = dyn;
     double *Km = lo.km >= 0 ? dyn + lo.km : Km_g, *Bm = lo.bm >= 0 ? dyn + lo.bm : Bm_g, *Qm = lo.qm >= 0 ? dyn + lo.qm : Qm_g,
            *Rm = lo.rm >= 0 ? dyn + lo.rm : Rm_g;
@@ -485,12 +514,19 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
     double prev = INFINITY;
     bool ok = false;
     int steps = 0;
+    const bool all_lds = lo.km >= 0 && lo.bm >= 0 && lo.qm >= 0 && lo.rm >= 0;   // Benzene-sized problems: everything the loop touches
     for (int it = 0; it < a.max_inner; ++it) {
-        wg_gemm(nv, no, nv, Avv, n, 1, Km, no, 1, 1.0, 1.0, Avo, n, Qm, no);
-        wg_gemm(no, no, nv, Aov, n, 1, Km, no, 1, 1.0, 1.0, Aoo, n, Bm, no);
+        if (all_lds) {
+            wg_gemm_lds(nv, no, nv, Avv, n, 1, Km, no, 1, 1.0, 1.0, Avo, n, Qm, no);
+            wg_gemm_lds(no, no, nv, Aov, n, 1, Km, no, 1, 1.0, 1.0, Aoo, n, Bm, no);
+        } else {
+            wg_gemm(nv, no, nv, Avv, n, 1, Km, no, 1, 1.0, 1.0, Avo, n, Qm, no);
+            wg_gemm(no, no, nv, Aov, n, 1, Km, no, 1, 1.0, 1.0, Aoo, n, Bm, no);
+        }
         __syncthreads();
         if (it == 0) QCDFT_STAMP(2);
-        wg_gemm(nv, no, no, Km, no, 1, Bm, no, 1, -1.0, 1.0, Qm, no, Rm, no);
+        if (all_lds) wg_gemm_lds(nv, no, no, Km, no, 1, Bm, no, 1, -1.0, 1.0, Qm, no, Rm, no);
+        else         wg_gemm(nv, no, no, Km, no, 1, Bm, no, 1, -1.0, 1.0, Qm, no, Rm, no);
         __syncthreads();
         if (it == 0) QCDFT_STAMP(3);
         double r = 0.0, rv[EPT];
@@ -502,17 +538,18 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
             r = fmax(r, x);
             if (!(x == x)) r = INFINITY;
         }
+        // the tentative update goes into the spare copy while the maximum is being agreed on (one barrier pair for both)
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = t + k * TL_ROT_T;
+            if (e < nk) Rm[e] = Km[e] - rv[k] * rd[k];
+        }
         r = block_max(r, red);
         ++steps;
         if (r < a.tol) { ok = true; break; }
         if (!(r < 4.0 * prev)) break;   // diverging (or NaN)
         prev = fmin(prev, r);
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            const int e = t + k * TL_ROT_T;
-            if (e < nk) Km[e] -= rv[k] * rd[k];
-        }
-        __syncthreads();
+        { double *tmp = Km; Km = Rm; Rm = tmp; }   // K <- K - R / (a_v - a_o); the old K's space takes the next residual
         if (it == 0) QCDFT_STAMP(4);
     }
     QCDFT_STAMP(5);
@@ -531,8 +568,13 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
     double *Fo = cm, *Pm = cm + n2o, *W1 = cm + 2 * n2o, *Fop = cm + 3 * n2o, *Vo = cm + 4 * n2o, *cd = cm + 5 * n2o, *Xm = cm + 6 * n2o,
            *Lig = cm + 7 * n2o, *L1g = cm + 8 * n2o, *MX = cm + 9 * n2o;
     // Fo = Y^T F Y in the U basis (Y = Uo + Uv K), M = K^T K (P = Y^T Y = 1 + M)
-    wg_gemm(no, no, nv, Km, 1, no, Qm, no, 1, 1.0, 1.0, Bm, no, Fo, no);
-    wg_gemm(no, no, nv, Km, 1, no, Km, no, 1, 1.0, 0.0, nullptr, 0, Pm, no);
+    if (all_lds) {
+        wg_gemm_lds(no, no, nv, Km, 1, no, Qm, no, 1, 1.0, 1.0, Bm, no, Fo, no);
+        wg_gemm_lds(no, no, nv, Km, 1, no, Km, no, 1, 1.0, 0.0, Km, 0, Pm, no);
+    } else {
+        wg_gemm(no, no, nv, Km, 1, no, Qm, no, 1, 1.0, 1.0, Bm, no, Fo, no);
+        wg_gemm(no, no, nv, Km, 1, no, Km, no, 1, 1.0, 0.0, nullptr, 0, Pm, no);
+    }
     __syncthreads();
     QCDFT_STAMP(6);
     chol_and_inverses(no, Pm, Lm, Li, L1);
@@ -544,9 +586,9 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
     }
     __syncthreads();
     // G = L^-1 Fo L^-T
-    wg_gemm(no, no, no, Lig, no, 1, Fo, no, 1, 1.0, 0.0, nullptr, 0, W1, no);
+    wg_gemm_lds(no, no, no, Lig, no, 1, Fo, no, 1, 1.0, 0.0, Fo, 0, W1, no);
     __syncthreads();
-    wg_gemm(no, no, no, W1, no, 1, Lig, 1, no, 1.0, 0.0, nullptr, 0, Fop, no);
+    wg_gemm_lds(no, no, no, W1, no, 1, Lig, 1, no, 1.0, 0.0, Fo, 0, Fop, no);
     __syncthreads();
     QCDFT_STAMP(8);
     // One-sided Jacobi on the columns of G - sigma (sigma above the spectrum: all eigenvalues of one sign, so orthogonal
@@ -561,6 +603,13 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
             gs = rs;
         }
         const double sigma = block_max(gs, red) + 1.0;   // Gershgorin bound on |lambda|, plus a margin
+        // An occupied block that is diagonal to canon_tol (Hartree) already is left as it is: the fixed point's denominators
+        // only cross the gap, where off-diagonal elements of that size do not count (the virtual block is never diagonalised
+        // at all), and the orbital energies reported are Rayleigh quotients, exact to second order.
+        double off = 0.0;
+        for (int e = t; e < n2o; e += TL_ROT_T)
+            if (e / no != e % no) off = fmax(off, fabs(0.5 * (Fop[e] + Fop[(e % no) * no + e / no])));
+        const bool skip_sweeps = block_max(off, red) <= a.canon_tol;
         for (int e = t; e < TL_MAXO * TL_MAXO; e += TL_ROT_T) {
             const int j = e / TL_MAXO, i = e - j * TL_MAXO;   // column j, row i
             double g = 0.0;
@@ -575,7 +624,7 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
         // next cycle's denominators want no more, and the orbitals are exactly orthonormal whatever the rotations were).
         const double stop2 = a.canon_tol * a.canon_tol, skip2 = 1e-26;
         int sweeps = 0;
-        for (int sweep = 0; sweep < 12; ++sweep) {
+        for (int sweep = 0; sweep < 12 && !skip_sweeps; ++sweep) {
             int big = 0;
             for (int round = 0; round < ne - 1; ++round) {
                 const int pr = 2 * wave + (lane >> 5);   // sixteen pairs at a time
@@ -643,12 +692,17 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
     //   U_o' = (U_o + U_v K) c,   c = L^-T V                      ->  W[:, :no] = [c; K c]
     //   U_v' = T (1 + K X K^T),   T = U_v - U_o K^T, X = -L^-T (1 + L)^-1  ->  W[:, no:] = [-(1 + M X) K^T; 1 + (K X) K^T]
     double *Kc = Qm, *KX = Rm;   // Q and R are done with
-    wg_gemm(no, no, no, Lig, 1, no, Vo, no, 1, 1.0, 0.0, nullptr, 0, cd, no);          // c = L^-T V
-    wg_gemm(no, no, no, Lig, 1, no, L1g, no, 1, -1.0, 0.0, nullptr, 0, Xm, no);        // X = -L^-T (1 + L)^-1
+    wg_gemm_lds(no, no, no, Lig, 1, no, Vo, no, 1, 1.0, 0.0, Vo, 0, cd, no);           // c = L^-T V
+    wg_gemm_lds(no, no, no, Lig, 1, no, L1g, no, 1, -1.0, 0.0, Vo, 0, Xm, no);         // X = -L^-T (1 + L)^-1
     __syncthreads();
-    wg_gemm(nv, no, no, Km, no, 1, cd, no, 1, 1.0, 0.0, nullptr, 0, Kc, no);
-    wg_gemm(nv, no, no, Km, no, 1, Xm, no, 1, 1.0, 0.0, nullptr, 0, KX, no);
-    wg_gemm(no, no, no, Pm, no, 1, Xm, no, 1, 1.0, 0.0, nullptr, 0, MX, no);           // M X
+    if (all_lds) {
+        wg_gemm_lds(nv, no, no, Km, no, 1, cd, no, 1, 1.0, 0.0, cd, 0, Kc, no);
+        wg_gemm_lds(nv, no, no, Km, no, 1, Xm, no, 1, 1.0, 0.0, cd, 0, KX, no);
+    } else {
+        wg_gemm(nv, no, no, Km, no, 1, cd, no, 1, 1.0, 0.0, nullptr, 0, Kc, no);
+        wg_gemm(nv, no, no, Km, no, 1, Xm, no, 1, 1.0, 0.0, nullptr, 0, KX, no);
+    }
+    wg_gemm_lds(no, no, no, Pm, no, 1, Xm, no, 1, 1.0, 0.0, cd, 0, MX, no);            // M X
     for (int e = t; e < n2o; e += TL_ROT_T) W[(size_t)(e / no) * n + e % no] = cd[e];
     __syncthreads();
     for (int e = t; e < n2o; e += TL_ROT_T) MX[e] += e / no == e % no ? 1.0 : 0.0;     // 1 + M X
@@ -659,6 +713,7 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
     __syncthreads();
     if (t < nv) W[(size_t)(no + t) * n + no + t] += 1.0;                                              // ... + 1
     QCDFT_STAMP(10);
+    if (threadIdx.x == 0) stamps[12] = (long long)clock64();
 #undef QCDFT_STAMP
 }
 

@@ -780,7 +780,7 @@ def _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     rotate, last_ddm = True, None
     d_K = backend.d_K if want_k else None
     d_exc = t.zeros(1, dtype=t.float64, device=backend.dev)
-    marks = []                                                                         # (start, J/K done, XC done) events per cycle
+    marks, tail_log = [], []                                                           # (start, J/K done, XC done) events; (status, fixed-point steps, Jacobi sweeps)
     sol = backend.solver
     for cycle in range(max_cycle):
         t_it = time.time()
@@ -798,7 +798,8 @@ def _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         marks.append(ev)
         tol = 1e-10 if last_ddm is None else min(max(1e-10, 1e-3 * last_ddm), 1e-5)    # as OccupiedRotation.occupied(accuracy)
         tail.step(rotate, c_hf, tol, backend.d_J, d_K, backend.d_v, backend.d_dm, backend.d_cocc, d_exc=d_exc)
-        E_one, E_coul, E_ex, ddm, status, steps, _, E_xc = tail.wait()
+        E_one, E_coul, E_ex, ddm, status, steps, sweeps, E_xc = tail.wait()
+        tail_log.append((status, steps, sweeps))
         if status == 2:                                                                # singular Pulay system: least squares on the host
             tail.step(rotate, c_hf, tol, backend.d_J, d_K, backend.d_v, backend.d_dm, backend.d_cocc,
                       coef=tail.pulay_coefficients_on_host(), repeat=True)
@@ -837,6 +838,7 @@ def _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     res["dm"] = backend.d_dm.cpu().numpy()
     res["mo_energy"] = np.asarray(e)
     res["loop"] = "fused"
+    res["tail_log"] = tail_log
     for ev in marks:                                                                   # device-side durations: nothing waited in between
         jk_times.append(1e-3 * ev[0].elapsed_time(ev[1])); xc_times.append(1e-3 * ev[1].elapsed_time(ev[2]))
     return _finish(res, t_start, xc_times, jk_times, it_times)

@@ -32,4 +32,5 @@ for cyc in range(6):
     o = tail.wait(); wall = time.perf_counter() - t0
     st = (ctypes.c_longlong * 16)(); lib.DFT_ScfTailStamps(tail._h, st)
     d = [(st[k] - st[k - 1]) / 100.0 for k in range(1, 11)]
-    print(f"cycle {cyc}: status {o[4]} steps {o[5]} sweeps {o[6]} wall {1e6 * wall:.0f} us; rot phases (us): " + ", ".join(f"{nm} {x:.1f}" for nm, x in zip(names[1:], d)), flush=True)
+    print(f"cycle {cyc}: status {o[4]} steps {o[5]} sweeps {o[6]} wall {1e6 * wall:.0f} us; rot phases (us): " + ", ".join(f"{nm} {x:.1f}" for nm, x in zip(names[1:], d))
+          + f"; core clock {(st[12] - st[11]) / max(1, st[10] - st[0]) * 100:.0f} MHz", flush=True)
