@@ -391,15 +391,23 @@ def scf_real_sharded_leg(lib_path, dev, world, rank, molecule="Anthracene", func
     t0 = time.perf_counter()
     inp = inputs.build(molecule, basis_name, 3, device=dev, verbose=False, eri_mode="cholesky", chol_tol=tol, rank=rank, world=world)
     t_build = time.perf_counter() - t0
-    abi = None
+    abi = torch_loop = None
     if world == 1:   # the same SCF with the reference ABI's DFT_ComputeXC (full density matrix) in the sweep, beside the default
         be = scf.HipBackend(inp, functional, lib_path, device=dev, xc_occ=False)
         ra = scf.run_scf(inp, be, functional, log=None)
-        abi = {"xc_entry_point": "DFT_ComputeXC", "ms_per_cycle": ra["iter_ms"], "xc_ms": ra["xc_ms"], "jk_ms": ra["jk_ms"], "cycles": ra["cycles"], "E_tot": ra["E_tot"]}
+        abi = {"xc_entry_point": "DFT_ComputeXC", "ms_per_cycle": ra["iter_ms"], "xc_ms": ra["xc_ms"], "jk_ms": ra["jk_ms"], "cycles": ra["cycles"], "E_tot": ra["E_tot"],
+               "loop": ra.get("loop", "device")}
+        del be
+        # ... and with rounds 2-3's device-resident loop (Fock assembly, DIIS and the rotation as torch operations) instead of the tail kernels
+        be = scf.HipBackend(inp, functional, lib_path, device=dev, fused_tail=False)
+        rt = scf.run_scf(inp, be, functional, log=None)
+        torch_loop = {"ms_per_cycle": rt["iter_ms"], "xc_ms": rt["xc_ms"], "jk_ms": rt["jk_ms"], "cycles": rt["cycles"], "E_tot": rt["E_tot"],
+                      "eigensolver": dict(be.occ_solver.stats) if be.occ_solver is not None else None}
         del be
     be = scf.HipBackend(inp, functional, lib_path, rank=rank, world=world, device=dev)
     r = scf.run_scf(inp, be, functional, log=None)
-    out = {"xc_entry_point": "DFT_ComputeXCOcc (occupied orbitals; scf.HipBackend default)", "abi_xc_entry": abi,
+    out = {"xc_entry_point": "DFT_ComputeXCOcc (occupied orbitals; scf.HipBackend default)", "abi_xc_entry": abi, "torch_loop": torch_loop,
+           "loop": r.get("loop", "device-resident torch loop" if be.device_resident else "host"),
            "workload": f"{molecule} {functional}/{basis_name}: nao {inp.shells.nao}, {inp.grids.size} grid points, {(inp.chol_range[2] if inp.chol_range else inp.chol.shape[0])} Cholesky vectors "
                        f"({tol:g}), sharded over {world} GPU(s); inputs built in {t_build:.1f} s (not timed; the Cholesky factorisation on rank 0 alone, "
                        f"vector slices sent to the ranks)",

@@ -221,7 +221,8 @@ void DFT_EriColumnsClose(void *handle);
  * reference's loop runs on the host -- Fock assembly (dft.py:212-223), Pulay DIIS (dft.py:225), eigh(F, S) (dft.py:227),
  * dm = 2 C_occ C_occ^T (dft.py:228) and the energy traces (dft.py:231-234).  DFT_ScfTailStep queues all of it behind
  * the kernels that produced J, K and Vxc (csrc/scf_tail.hip): the eigenproblem as the occupied-subspace rotation of
- * scf.OccupiedRotation from the basis in d_basis.  For 2 <= nao <= 128, 1 <= nocc <= 32 (NULL from Open otherwise).
+ * scf.OccupiedRotation from the basis in d_basis.  For 2 <= nao <= 512, 1 <= nocc <= 64 (NULL from Open otherwise; up to
+ * 128 x 32 the rotation's matrices live in LDS, above in memory).
  *   Open    hcore, overlap: (nao, nao) device, read in every step; d_basis: (nao, nao) device, columns = an
  *           S-orthonormal basis whose first nocc columns span the occupied space (the eigenvectors of the last full
  *           diagonalisation, uploaded by the caller; replaced by the rotated basis after every successful step);

@@ -35,11 +35,14 @@ using namespace qcdft;
 
 namespace {
 
-constexpr int TL_MAXN = 128;   // basis functions (LDS rows of the strip kernels, diagonal in k_tail_rot)
-constexpr int TL_MAXO = 32;    // occupied orbitals (one wave per Jacobi pair, LDS copies of the small matrices)
+constexpr int TL_MAXN = 128;   // basis functions of the LDS-resident rotation kernel (k_tail_rot)
+constexpr int TL_MAXO = 32;    // occupied orbitals of it (half a wave per Jacobi pair, LDS copies of the small matrices)
+constexpr int TL_BIGN = 512;   // ... of the memory-resident one (k_tail_rot_big) and of every other kernel here
+constexpr int TL_BIGO = 64;
 constexpr int TL_SPACE = 8;    // DIIS ring
-constexpr int TL_ROT_T = 512;  // threads of k_tail_rot (eight waves: 256 registers each)
+constexpr int TL_ROT_T = 512;  // threads of the rotation kernels (eight waves: 256 registers each)
 constexpr int TL_LD = TL_MAXO + 1;
+constexpr int TL_BLD = TL_BIGO + 1;
 
 struct TailArgs {
     int n, no, slot, nhist, have_coef, rotate, max_inner;
@@ -57,7 +60,8 @@ struct TailDev {
     const double *H = nullptr, *S = nullptr;
     double *U = nullptr, *Fx = nullptr, *eig = nullptr;       // caller's
     double *blob = nullptr;                                   // everything below
-    double *Fb, *Eb, *Gb, *FC, *SC, *gpart, *FU, *A, *Unew, *Km, *Rm, *Qm, *Bm, *epart;
+    double *Fb, *Eb, *Gb, *FC, *SC, *gpart, *FU, *A, *Unew, *Km, *Rm, *Qm, *Bm, *epart, *rden, *smalls, *Kfix, *KXg, *Kt, *Kt2, *K2;
+    bool big = false;           // k_tail_rot_big: operands in memory
     int *status = nullptr;     // [0] status, [1] inner steps, [2] Jacobi sweeps, [3] ticket
     double *h_out = nullptr, *h_out_dev = nullptr;            // host-mapped: 8 doubles + sequence word
     unsigned long seq = 0;
@@ -84,19 +88,18 @@ __device__ __forceinline__ double bcast(double v, int l)
     return __hiloint2double(hi, lo);
 }
 
-// F row i into ring slot `slot`; (F c)[i, :] and (S c)[i, :].  Thread (o, q): orbital o, quarter... eighth q of the j range.
+// F row i into ring slot `slot`; (F c)[i, :] and (S c)[i, :].  Thread (o, q): orbital o, quarter q of the j range.
 __global__ __launch_bounds__(256) void k_tail_fock(TailArgs a, const double *__restrict__ H, const double *__restrict__ S,
                                                    const double *__restrict__ J, const double *__restrict__ Kx,
                                                    const double *__restrict__ V, const double *__restrict__ c,
                                                    double *__restrict__ Fb, double *__restrict__ FC, double *__restrict__ SC,
                                                    int *__restrict__ status)
 {
-    __shared__ double frow[TL_MAXN], srow[TL_MAXN], pf[8][TL_MAXO], ps[8][TL_MAXO];
+    __shared__ double frow[TL_BIGN], srow[TL_BIGN], pf[4][TL_BIGO], ps[4][TL_BIGO];
     const int n = a.n, no = a.no, i = blockIdx.x, t = threadIdx.x;
     if (i == 0 && t == 0) { status[0] = 0; status[1] = 0; status[2] = 0; }   // read by the kernels behind this one only
     double *F = Fb + (size_t)a.slot * n * n;
-    if (t < n) {
-        const int j = t;
+    for (int j = t; j < n; j += 256) {
         double f = H[i * n + j] + J[i * n + j] + 0.5 * (V[i * n + j] + V[j * n + i]);   // dft.py:212,223
         if (Kx) f -= 0.5 * a.c_hf * Kx[i * n + j];                                     // dft.py:221
         F[i * n + j] = f;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void k_tail_fock(TailArgs a, const double *__r
         srow[j] = S[i * n + j];
     }
     __syncthreads();
-    const int o = t & 31, q = t >> 5, per = (n + 7) >> 3, j0 = q * per, j1 = min(n, j0 + per);
+    const int o = t & 63, q = t >> 6, per = (n + 3) >> 2, j0 = q * per, j1 = min(n, j0 + per);
     double fc = 0.0, sc = 0.0;
     if (o < no)
         for (int j = j0; j < j1; ++j) {
@@ -116,11 +119,8 @@ __global__ __launch_bounds__(256) void k_tail_fock(TailArgs a, const double *__r
     ps[q][o] = sc;
     __syncthreads();
     if (t < no) {
-        double x = 0.0, y = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { x += pf[k][t]; y += ps[k][t]; }
-        FC[i * no + t] = x;
-        SC[i * no + t] = y;
+        FC[i * no + t] = (pf[0][t] + pf[1][t]) + (pf[2][t] + pf[3][t]);
+        SC[i * no + t] = (ps[0][t] + ps[1][t]) + (ps[2][t] + ps[3][t]);
     }
 }
 
@@ -129,33 +129,42 @@ __global__ __launch_bounds__(256) void k_tail_fock(TailArgs a, const double *__r
 __global__ __launch_bounds__(128) void k_tail_err(TailArgs a, const double *__restrict__ FC, const double *__restrict__ SC,
                                                   double *__restrict__ Eb, double *__restrict__ gpart)
 {
-    __shared__ double fci[TL_MAXO], sci[TL_MAXO], part[2][TL_SPACE];
+    __shared__ double fci[TL_BIGO], sci[TL_BIGO], part[2][TL_SPACE];
     const int n = a.n, no = a.no, i = blockIdx.x, t = threadIdx.x;
-    if (t < TL_MAXO) { fci[t] = t < no ? FC[i * no + t] : 0.0; sci[t] = t < no ? SC[i * no + t] : 0.0; }
+    if (t < TL_BIGO) { fci[t] = t < no ? FC[i * no + t] : 0.0; sci[t] = t < no ? SC[i * no + t] : 0.0; }
     __syncthreads();
     double *E = Eb + (size_t)a.slot * n * n;
-    double e = 0.0;
-    const int j = t;
-    if (j < n) {
-        double sj[TL_MAXO], fj[TL_MAXO];
+    double gp[TL_SPACE];
 #pragma unroll
-        for (int o = 0; o < TL_MAXO; ++o) {   // every load first: one memory round trip, not n_occ of them
-            sj[o] = o < no ? SC[j * no + o] : 0.0;
-            fj[o] = o < no ? FC[j * no + o] : 0.0;
+    for (int s = 0; s < TL_SPACE; ++s) gp[s] = 0.0;
+    for (int j = t; j < n; j += 128) {
+        double e = 0.0;
+#pragma unroll
+        for (int h0 = 0; h0 < TL_BIGO; h0 += 32) {   // thirty-two orbitals' loads first: one memory round trip, not n_occ of them
+            if (h0 < no) {
+                double sj[32], fj[32];
+#pragma unroll
+                for (int o = 0; o < 32; ++o) {
+                    sj[o] = h0 + o < no ? SC[j * no + h0 + o] : 0.0;
+                    fj[o] = h0 + o < no ? FC[j * no + h0 + o] : 0.0;
+                }
+#pragma unroll
+                for (int o = 0; o < 32; ++o) e += fci[h0 + o] * sj[o] - sci[h0 + o] * fj[o];
+            }
+        }
+        E[i * n + j] = e;
+        double eh[TL_SPACE];
+#pragma unroll
+        for (int s = 0; s < TL_SPACE; ++s) {
+            const int h = a.hist[s < a.nhist ? s : 0];
+            eh[s] = s < a.nhist ? (h == a.slot ? e : Eb[(size_t)h * n * n + (size_t)i * n + j]) : 0.0;
         }
 #pragma unroll
-        for (int o = 0; o < TL_MAXO; ++o) e += fci[o] * sj[o] - sci[o] * fj[o];
-        E[i * n + j] = e;
-    }
-    double eh[TL_SPACE];
-#pragma unroll
-    for (int s = 0; s < TL_SPACE; ++s) {
-        const int h = a.hist[s < a.nhist ? s : 0];
-        eh[s] = (s < a.nhist && j < n) ? (h == a.slot ? e : Eb[(size_t)h * n * n + (size_t)i * n + j]) : 0.0;
+        for (int s = 0; s < TL_SPACE; ++s) gp[s] = fma(eh[s], e, gp[s]);
     }
 #pragma unroll
     for (int s = 0; s < TL_SPACE; ++s) {
-        const double p = wave_sum(eh[s] * e);
+        const double p = wave_sum(gp[s]);
         if ((t & 63) == 0) part[t >> 6][s] = p;
     }
     __syncthreads();
@@ -263,24 +272,24 @@ __global__ __launch_bounds__(128) void k_tail_mix(TailArgs a, const double *__re
         if (i == 0 && t == 0) status[0] = 2;
         return;
     }
-    if (t < n) {
+    for (int j = t; j < n; j += 128) {
         double fb[TL_SPACE];
 #pragma unroll
-        for (int s = 0; s < TL_SPACE; ++s) fb[s] = s < m ? Fb[(size_t)a.hist[s] * n * n + (size_t)i * n + t] : 0.0;
+        for (int s = 0; s < TL_SPACE; ++s) fb[s] = s < m ? Fb[(size_t)a.hist[s] * n * n + (size_t)i * n + j] : 0.0;
         double f = 0.0;
 #pragma unroll
         for (int s = 0; s < TL_SPACE; ++s)
             if (s < m) f = fma(cf[s], fb[s], f);
-        Fx[i * n + t] = f;
+        Fx[i * n + j] = f;
     }
 }
 
 // One 16 x 16 tile of C (M x N) = A B per workgroup on the fp64 matrix cores, the contraction split over four waves
-// (K <= 128: at most eight steps of four each, all operands loaded before the first MFMA): A(i, k) = a[i ars + k acs],
-// B(k, j) = b[k brs + j bcs].
+// (thirty-two contraction steps per round: eight per wave, all operands loaded before the round's first MFMA):
+// A(i, k) = a[i ars + k acs], B(k, j) = b[k brs + j bcs].
 __global__ __launch_bounds__(256) void k_tail_gemm(int M, int N, int Kd, const double *__restrict__ a, int ars, int acs,
                                                    const double *__restrict__ b, int brs, int bcs, double *__restrict__ c, int ldc,
-                                                   const int *__restrict__ status)
+                                                   double alpha, int add_diag, const int *__restrict__ status)
 {
     __shared__ double part[4][4][64];
     if (status[0] != 0) return;
@@ -288,24 +297,31 @@ __global__ __launch_bounds__(256) void k_tail_gemm(int M, int N, int Kd, const d
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
     const int ia = i0 + li, jb = j0 + li;
     const bool aok = ia < M, bok = jb < N;
-    double av[8], bv[8];
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < Kd; k0 += 128) {
+        double av[8], bv[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int k = 4 * (4 * s + wave) + kq;
-        av[s] = aok && k < Kd ? a[(size_t)ia * ars + (size_t)k * acs] : 0.0;
-        bv[s] = bok && k < Kd ? b[(size_t)k * brs + (size_t)jb * bcs] : 0.0;
+        for (int s = 0; s < 8; ++s) {
+            const int k = k0 + 4 * (4 * s + wave) + kq;
+            av[s] = aok && k < Kd ? a[(size_t)ia * ars + (size_t)k * acs] : 0.0;
+            bv[s] = bok && k < Kd ? b[(size_t)k * brs + (size_t)jb * bcs] : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; s += 2) {
+            acc0 = mfma_f64(av[s], bv[s], acc0);
+            acc1 = mfma_f64(av[s + 1], bv[s + 1], acc1);
+        }
     }
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc = mfma_f64(av[s], bv[s], acc);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
+    for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc0[r] + acc1[r];
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = i0 + kq + 4 * r, col = j0 + li;
-            if (row < M && col < N) c[(size_t)row * ldc + col] = (part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane]);
+            if (row < M && col < N)
+                c[(size_t)row * ldc + col] = alpha * ((part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane])) +
+                                             (add_diag && row == col ? 1.0 : 0.0);
         }
     }
 }
@@ -341,21 +357,37 @@ __device__ __forceinline__ void wg_gemm_t(int M, int N, int Kd, const double *a_
         const bool aok = ia < M, bok = jb < N;
         const int aoff = (aok ? ia : 0) * ars, boff = (bok ? jb : 0) * bcs;
         d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        for (int k0 = 0; k0 < Kd; k0 += 32) {
-            double av[8], bv[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int k = k0 + 4 * s + kq;
-                const bool kok = k < Kd;
-                av[s] = aok && kok ? a[aoff + k * acs] : 0.0;
-                bv[s] = bok && kok ? b[boff + k * brs] : 0.0;
-            }
-#pragma unroll
-            for (int s = 0; s < 8; s += 2) {
-                acc0 = mfma_f64(av[s], bv[s], acc0);
-                acc1 = mfma_f64(av[s + 1], bv[s + 1], acc1);
-            }
+        // two operand sets in turn: the next eight steps' loads are in flight while this set's MFMAs run
+        double av0[8], bv0[8], av1[8], bv1[8];
+#define QCDFT_TL_LOAD(AV, BV, K0)                                       \
+    _Pragma("unroll") for (int s = 0; s < 8; ++s) {                     \
+        const int k = (K0) + 4 * s + kq;                                \
+        const bool kok = k < Kd;                                        \
+        AV[s] = aok && kok ? a[aoff + k * acs] : 0.0;                   \
+        BV[s] = bok && kok ? b[boff + k * brs] : 0.0;                   \
+    }
+#define QCDFT_TL_MMA(AV, BV)                                            \
+    _Pragma("unroll") for (int s = 0; s < 8; s += 2) {                  \
+        acc0 = mfma_f64(AV[s], BV[s], acc0);                            \
+        acc1 = mfma_f64(AV[s + 1], BV[s + 1], acc1);                    \
+    }
+        QCDFT_TL_LOAD(av0, bv0, 0)
+        for (int k0 = 0;;) {
+            if (k0 + 32 < Kd) { QCDFT_TL_LOAD(av1, bv1, k0 + 32) }
+            __builtin_amdgcn_sched_barrier(0);
+            QCDFT_TL_MMA(av0, bv0)
+            __builtin_amdgcn_sched_barrier(0);
+            k0 += 32;
+            if (k0 >= Kd) break;
+            if (k0 + 32 < Kd) { QCDFT_TL_LOAD(av0, bv0, k0 + 32) }
+            __builtin_amdgcn_sched_barrier(0);
+            QCDFT_TL_MMA(av1, bv1)
+            __builtin_amdgcn_sched_barrier(0);
+            k0 += 32;
+            if (k0 >= Kd) break;
         }
+#undef QCDFT_TL_LOAD
+#undef QCDFT_TL_MMA
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = i0 + kq + 4 * r, col = j0 + li;
@@ -367,12 +399,12 @@ __device__ __forceinline__ void wg_gemm_t(int M, int N, int Kd, const double *a_
         }
     }
 }
-__device__ void wg_gemm(int M, int N, int Kd, const double *a, int ars, int acs, const double *b, int brs, int bcs,
+__device__ __forceinline__ void wg_gemm(int M, int N, int Kd, const double *a, int ars, int acs, const double *b, int brs, int bcs,
                         double alpha, double beta, const double *d, int ldd, double *c, int ldc)
 {
     wg_gemm_t<false>(M, N, Kd, a, ars, acs, b, brs, bcs, alpha, beta, d, ldd, c, ldc);
 }
-__device__ void wg_gemm_lds(int M, int N, int Kd, const double *a, int ars, int acs, const double *b, int brs, int bcs,
+__device__ __forceinline__ void wg_gemm_lds(int M, int N, int Kd, const double *a, int ars, int acs, const double *b, int brs, int bcs,
                             double alpha, double beta, const double *d, int ldd, double *c, int ldc)
 {
     wg_gemm_t<true>(M, N, Kd, a, ars, acs, b, brs, bcs, alpha, beta, d, ldd, c, ldc);
@@ -398,37 +430,38 @@ __device__ __forceinline__ double half_sum(double v)
 
 // Cholesky P = L L^T in the registers of wave 0 (lane i holds row i; the trailing update takes L[k][j] from lane k),
 // then L^-1 (wave 0) and (1 + L)^-1 (wave 1), one column per lane by forward substitution.
-__device__ __forceinline__ void chol_and_inverses(int no, const double *Pm, double (*Lm)[TL_LD], double (*Li)[TL_LD], double (*L1)[TL_LD])
+template <int MAXO>
+__device__ __forceinline__ void chol_and_inverses(int no, const double *Pm, double (*Lm)[MAXO + 1], double (*Li)[MAXO + 1], double (*L1)[MAXO + 1])
 {
     const int t = threadIdx.x;
     if (t < 64) {
         const int lane = t;
-        double r[TL_MAXO];
+        double r[MAXO];
 #pragma unroll
-        for (int j = 0; j < TL_MAXO; ++j)
+        for (int j = 0; j < MAXO; ++j)
             r[j] = (lane < no && j < no) ? 0.5 * (Pm[lane * no + j] + Pm[j * no + lane]) + (lane == j ? 1.0 : 0.0) : (lane == j ? 1.0 : 0.0);
 #pragma unroll
-        for (int j = 0; j < TL_MAXO; ++j) {
+        for (int j = 0; j < MAXO; ++j) {
             if (j < no) {
                 const double djj = sqrt(bcast(r[j], j));
                 r[j] = lane == j ? djj : (lane > j ? r[j] / djj : 0.0);
 #pragma unroll
-                for (int k = j + 1; k < TL_MAXO; ++k)
+                for (int k = j + 1; k < MAXO; ++k)
                     if (k < no) r[k] -= r[j] * bcast(r[j], k);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
-        for (int j = 0; j < TL_MAXO; ++j)
-            if (lane < TL_MAXO) Lm[lane][j] = j <= lane ? r[j] : 0.0;
+        for (int j = 0; j < MAXO; ++j)
+            if (lane < MAXO) Lm[lane][j] = j <= lane ? r[j] : 0.0;
     }
     __syncthreads();
     if (t < 128) {
         const int lane = t & 63;
         const bool plus = t >= 64;
-        double x[TL_MAXO];
+        double x[MAXO];
 #pragma unroll
-        for (int i = 0; i < TL_MAXO; ++i) {
+        for (int i = 0; i < MAXO; ++i) {
             double s = lane == i ? 1.0 : 0.0;
             x[i] = lane == i ? 1.0 : 0.0;                                    // rows past n_occ: the identity
             if (i < no) {
@@ -438,10 +471,10 @@ __device__ __forceinline__ void chol_and_inverses(int no, const double *Pm, doub
             }
             __builtin_amdgcn_sched_barrier(0);                               // row by row: hoisting every row's loads costs registers
         }
-        double (*Out)[TL_LD] = plus ? L1 : Li;
+        double (*Out)[MAXO + 1] = plus ? L1 : Li;
 #pragma unroll
-        for (int i = 0; i < TL_MAXO; ++i)
-            if (lane < TL_MAXO) Out[i][lane] = x[i];
+        for (int i = 0; i < MAXO; ++i)
+            if (lane < MAXO) Out[i][lane] = x[i];
     }
     __syncthreads();
 }
@@ -577,7 +610,7 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
     }
     __syncthreads();
     QCDFT_STAMP(6);
-    chol_and_inverses(no, Pm, Lm, Li, L1);
+    chol_and_inverses<TL_MAXO>(no, Pm, Lm, Li, L1);
     QCDFT_STAMP(7);
     for (int e = t; e < n2o; e += TL_ROT_T) {
         const int i = e / no, j = e - i * no;
@@ -717,6 +750,213 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
 #undef QCDFT_STAMP
 }
 
+// The same rotation for sizes whose matrices do not fit the LDS (nao <= 512, nocc <= 64; Anthracene: 246 / 494 functions, 47
+// occupied): one workgroup again -- a barrier across workgroups costs 4 us plus 0.3 us per workgroup on this chip
+// (tools/gridsync_probe.hip, agent-scope fences either side), more than the phases it would separate -- with every operand in
+// memory (L2-resident: A is 0.5-2 MB) behind generic pointers, the n_occ x n_occ triangular matrices alone in LDS.
+__global__ __launch_bounds__(TL_ROT_T) void k_tail_rot_big(TailArgs a, const double *__restrict__ A, double *Km, double *K2, double *Kt,
+                                                           double *Kt2, double *Qt, double *Rt, double *Bt, double *rdt, double *smalls,
+                                                           double *W, double *eig, int *status, long long *stamps, double *Kfix, double *KXg)
+{
+#define QCDFT_STAMP(k) do { if (threadIdx.x == 0) stamps[k] = (long long)wall_clock64(); } while (0)
+    extern __shared__ double dyn[];   // L, L^-1, (1 + L)^-1; the Jacobi columns reuse the last two
+    __shared__ double dd[TL_BIGN], red[TL_ROT_T / 64];
+    __shared__ int flag[TL_ROT_T / 64];
+    const int n = a.n, no = a.no, nv = n - no, t = threadIdx.x, nk = nv * no, n2o = no * no;
+    if (status[0] != 0) return;
+    QCDFT_STAMP(0);
+    const double *Aoo = A, *Aov = A + no, *Avo = A + (size_t)no * n, *Avv = A + (size_t)no * n + no;
+    for (int i = t; i < n; i += TL_ROT_T) dd[i] = A[(size_t)i * n + i];
+    __syncthreads();
+    // K lives twice, as K[v][o] and as its transpose Kt[o][v]: with both, every large operand below is read along its rows
+    // (16 lanes x 8 B from one 128-byte line; the strided alternative touches 16 lines per load and is bound by that, 4x slower)
+    double kmax = 0.0;
+    for (int e = t; e < nk; e += TL_ROT_T) {   // e = o nv + v: the transposed layout
+        const int o = e / nv, v = e - o * nv;
+        const double rd = 1.0 / (dd[no + v] - dd[o]);
+        const double x = -Aov[(size_t)o * n + v] * rd;   // A is symmetric to rounding: Aov[o][v] for Avo[v][o]
+        rdt[e] = rd;
+        Kt[e] = x;
+        Km[(size_t)v * no + o] = x;
+        kmax = fmax(kmax, fabs(x));
+        if (!(fabs(x) <= 0.5)) kmax = 1.0;
+    }
+    kmax = block_max(kmax, red);
+    if (!(kmax <= 0.5)) {
+        if (t == 0) status[0] = 1;
+        return;
+    }
+    QCDFT_STAMP(1);
+    double prev = INFINITY;
+    bool ok = false;
+    int steps = 0;
+    for (int it = 0; it < a.max_inner; ++it) {
+        // Qt = (Avo + Avv K)^T = Aov + K^T Avv,  Bt = (Aoo + Aov K)^T = Aoo + K^T Avo   (A symmetric)
+        wg_gemm(no, nv, nv, Km, 1, no, Avv, n, 1, 1.0, 1.0, Aov, n, Qt, nv);
+        wg_gemm(no, no, nv, Km, 1, no, Avo, n, 1, 1.0, 1.0, Aoo, n, Bt, no);
+        __syncthreads();
+        if (it == 0) QCDFT_STAMP(2);
+        // Rt = (Q - K B)^T = Qt - Bt Kt
+        wg_gemm(no, nv, no, Bt, no, 1, Kt, nv, 1, -1.0, 1.0, Qt, nv, Rt, nv);
+        __syncthreads();
+        if (it == 0) QCDFT_STAMP(3);
+        double r = 0.0;
+        for (int e0 = 0; e0 < nk; e0 += 4 * TL_ROT_T) {   // four elements per thread in flight
+            double rv[4], kv[4], dv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k * TL_ROT_T + t;
+                rv[k] = e < nk ? Rt[e] : 0.0; kv[k] = e < nk ? Kt[e] : 0.0; dv[k] = e < nk ? rdt[e] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k * TL_ROT_T + t;
+                const double x = fabs(rv[k]);
+                r = fmax(r, x);
+                if (!(x == x)) r = INFINITY;
+                if (e < nk) {   // the tentative update, in both layouts
+                    const double kn = kv[k] - rv[k] * dv[k];
+                    Kt2[e] = kn;
+                    K2[(size_t)(e % nv) * no + e / nv] = kn;
+                }
+            }
+        }
+        r = block_max(r, red);
+        ++steps;
+        if (r < a.tol) { ok = true; break; }
+        if (!(r < 4.0 * prev)) break;
+        prev = fmin(prev, r);
+        { double *tmp = Km; Km = K2; K2 = tmp; tmp = Kt; Kt = Kt2; Kt2 = tmp; }
+        if (it == 0) QCDFT_STAMP(4);
+    }
+    QCDFT_STAMP(5);
+    if (t == 0) status[1] = steps;
+    if (!ok) {
+        if (t == 0) status[0] = 1;
+        return;
+    }
+    double (*Lm)[TL_BLD] = (double (*)[TL_BLD])dyn, (*Li)[TL_BLD] = (double (*)[TL_BLD])(dyn + TL_BIGO * TL_BLD),
+           (*L1)[TL_BLD] = (double (*)[TL_BLD])(dyn + 2 * TL_BIGO * TL_BLD);
+    double *Fo = smalls, *Pm = smalls + n2o, *W1 = smalls + 2 * n2o, *Fop = smalls + 3 * n2o, *Vo = smalls + 4 * n2o, *cd = smalls + 5 * n2o,
+           *Xm = smalls + 6 * n2o, *Lig = smalls + 7 * n2o, *L1g = smalls + 8 * n2o, *MX = smalls + 9 * n2o;
+    // Fo^T = Bt + Q^T K (the transpose does as well: only the symmetrised G = L^-1 Fo L^-T is used), M = K^T K
+    wg_gemm(no, no, nv, Qt, nv, 1, Km, no, 1, 1.0, 1.0, Bt, no, Fo, no);
+    wg_gemm(no, no, nv, Km, 1, no, Km, no, 1, 1.0, 0.0, nullptr, 0, Pm, no);
+    __syncthreads();
+    QCDFT_STAMP(6);
+    chol_and_inverses<TL_BIGO>(no, Pm, Lm, Li, L1);
+    QCDFT_STAMP(7);
+    for (int e = t; e < n2o; e += TL_ROT_T) {
+        const int i = e / no, j = e - i * no;
+        Lig[e] = Li[i][j];
+        L1g[e] = L1[i][j];
+    }
+    __syncthreads();
+    wg_gemm(no, no, no, Lig, no, 1, Fo, no, 1, 1.0, 0.0, nullptr, 0, W1, no);
+    __syncthreads();
+    wg_gemm(no, no, no, W1, no, 1, Lig, 1, no, 1.0, 0.0, nullptr, 0, Fop, no);
+    __syncthreads();
+    QCDFT_STAMP(8);
+    {
+        // Jacobi as in k_tail_rot, a whole wave per column pair (lane = row, up to 64 rows), eight pairs at a time
+        double (*Wc)[TL_BLD] = Li, (*Vc)[TL_BLD] = L1;   // their contents are in memory now
+        const int ne = (no + 1) & ~1, wave = t >> 6, lane = t & 63, npair = ne >> 1;
+        double gs = 0.0, off = 0.0;
+        if (t < no)
+            for (int j = 0; j < no; ++j) gs += fabs(0.5 * (Fop[t * no + j] + Fop[j * no + t]));
+        const double sigma = block_max(gs, red) + 1.0;
+        for (int e = t; e < n2o; e += TL_ROT_T)
+            if (e / no != e % no) off = fmax(off, fabs(0.5 * (Fop[e] + Fop[(e % no) * no + e / no])));
+        const bool skip_sweeps = block_max(off, red) <= a.canon_tol;
+        for (int e = t; e < TL_BIGO * TL_BIGO; e += TL_ROT_T) {
+            const int j = e / TL_BIGO, i = e - j * TL_BIGO;
+            double g = 0.0;
+            if (i < no && j < no) g = 0.5 * (Fop[i * no + j] + Fop[j * no + i]) - (i == j ? sigma : 0.0);
+            Wc[j][i] = g;
+            Vc[j][i] = i == j ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        const double stop2 = a.canon_tol * a.canon_tol, skip2 = 1e-26;
+        int sweeps = 0;
+        for (int sweep = 0; sweep < 12 && !skip_sweeps; ++sweep) {
+            int big = 0;
+            for (int round = 0; round < ne - 1; ++round) {
+                for (int pr = wave; pr < npair; pr += TL_ROT_T / 64) {
+                    const bool live = lane < ne;
+                    const int p = pr == 0 ? ne - 1 : (round + pr) % (ne - 1);
+                    const int q = pr == 0 ? round : (round - pr + (ne - 1)) % (ne - 1);
+                    const double wp = live ? Wc[p][lane] : 0.0, wq = live ? Wc[q][lane] : 0.0;
+                    const double vp = live ? Vc[p][lane] : 0.0, vq = live ? Vc[q][lane] : 0.0;
+                    const double al = wave_sum(wp * wp), be = wave_sum(wq * wq), ga = wave_sum(wp * wq);
+                    const double g2 = ga * ga, ab = al * be;
+                    if (live && g2 > skip2 * ab) {
+                        big |= g2 > stop2 * ab;
+                        const double zeta = 0.5 * (be - al) * fast_rcp(ga);
+                        const double az = fabs(zeta);
+                        const double hyp = az < 1e150 ? (1.0 + zeta * zeta) * fast_rsqrt(1.0 + zeta * zeta) : az;
+                        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * fast_rcp(az + hyp);
+                        const double cs = fast_rsqrt(1.0 + tt * tt), sn = cs * tt;
+                        Wc[p][lane] = cs * wp - sn * wq;
+                        Wc[q][lane] = sn * wp + cs * wq;
+                        Vc[p][lane] = cs * vp - sn * vq;
+                        Vc[q][lane] = sn * vp + cs * vq;
+                    }
+                }
+                __syncthreads();
+            }
+            ++sweeps;
+            const int any = __ballot(big) != 0;
+            if (lane == 0) flag[wave] = any;
+            __syncthreads();
+            int more = 0;
+            for (int k = 0; k < TL_ROT_T / 64; ++k) more |= flag[k];
+            __syncthreads();
+            if (!more) break;
+        }
+        if (t == 0) status[2] = sweeps;
+        for (int j = wave; j < no; j += TL_ROT_T / 64) {
+            const double sj = wave_sum(lane < ne ? Vc[j][lane] * Wc[j][lane] : 0.0);
+            if (lane == 0) dd[j] = sj + sigma;
+        }
+        for (int e = t; e < n2o; e += TL_ROT_T) {
+            const int i = e / no, j = e - i * no;
+            Vo[e] = Vc[j][i];
+        }
+        __syncthreads();
+    }
+    QCDFT_STAMP(9);
+    {
+        double eo = -INFINITY, dv = INFINITY;
+        for (int i = t; i < n; i += TL_ROT_T) {
+            if (i < no) eo = fmax(eo, dd[i]);
+            else dv = fmin(dv, dd[i]);
+        }
+        const double eomax = block_max(eo, red), dvmin = -block_max(-dv, red);
+        if (eomax > dvmin - 1e-3) {
+            if (t == 0) status[0] = 1;
+            return;
+        }
+    }
+    if (eig)
+        for (int i = t; i < n; i += TL_ROT_T) eig[i] = dd[i];
+    // W = [c, -(1 + M X) K^T; K c, 1 + (K X) K^T] (see k_tail_rot): the two left blocks and the small factors here, the two
+    // right blocks (n_virt columns: hundreds of tiles) by the launches behind this kernel, which read K, K X and 1 + M X
+    double *Kc = Qt;   // (n_virt x n_occ, row-major; Q is done with)
+    wg_gemm(no, no, no, Lig, 1, no, Vo, no, 1, 1.0, 0.0, nullptr, 0, cd, no);
+    wg_gemm(no, no, no, Lig, 1, no, L1g, no, 1, -1.0, 0.0, nullptr, 0, Xm, no);
+    for (int e = t; e < nk; e += TL_ROT_T) Kfix[e] = Km[e];   // wherever the iteration left K
+    __syncthreads();
+    wg_gemm(nv, no, no, Kfix, no, 1, cd, no, 1, 1.0, 0.0, nullptr, 0, Kc, no);
+    wg_gemm(nv, no, no, Kfix, no, 1, Xm, no, 1, 1.0, 0.0, nullptr, 0, KXg, no);
+    wg_gemm(no, no, no, Pm, no, 1, Xm, no, 1, 1.0, 0.0, nullptr, 0, MX, no);
+    for (int e = t; e < n2o; e += TL_ROT_T) W[(size_t)(e / no) * n + e % no] = cd[e];
+    __syncthreads();
+    for (int e = t; e < n2o; e += TL_ROT_T) MX[e] += e / no == e % no ? 1.0 : 0.0;
+    for (int e = t; e < nk; e += TL_ROT_T) W[(size_t)(no + e / no) * n + e % no] = Kc[e];
+    QCDFT_STAMP(10);
+#undef QCDFT_STAMP
+}
+
 // Row i of dm' = c' c'^T and of the energy traces; on success the new basis and orbitals replace the old ones.  The last
 // workgroup to finish adds the row partials in a fixed order and publishes them.
 __global__ __launch_bounds__(128) void k_tail_density(TailArgs a, int from_basis, unsigned long seq, const double *__restrict__ H,
@@ -724,29 +964,32 @@ __global__ __launch_bounds__(128) void k_tail_density(TailArgs a, int from_basis
                                                       double *U, const double *Unew, double *dm, double *cocc,
                                                       double *epart, int *status, const double *exc, double *out)
 {
-    __shared__ double ci[TL_MAXO], part[2][4];
+    __shared__ double ci[TL_BIGO], part[2][4];
     __shared__ int last;
     const int n = a.n, no = a.no, i = blockIdx.x, t = threadIdx.x;
     const int st = from_basis ? 0 : status[0];
     const double sc = 1.4142135623730951;           // dm = 2 C_occ C_occ^T (dft.py:182): cocc = sqrt(2) C_occ
     const double *src = from_basis ? U : Unew;      // the caller's freshly diagonalised basis, or the rotated one
-    const int lds = n;
     if (st == 0) {
-        if (t < TL_MAXO) ci[t] = t < no ? sc * src[(size_t)i * lds + t] : 0.0;
+        if (t < TL_BIGO) ci[t] = t < no ? sc * src[(size_t)i * n + t] : 0.0;
         __syncthreads();
         double p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0;
-        const int j = t;
-        if (j < n) {
-            double cj[TL_MAXO];
-#pragma unroll
-            for (int o = 0; o < TL_MAXO; ++o) cj[o] = o < no ? sc * src[(size_t)j * lds + o] : 0.0;
+        for (int j = t; j < n; j += 128) {
             const double dold = dm[i * n + j], h = H[i * n + j], jj = J[i * n + j], kk = Kx ? Kx[i * n + j] : 0.0;
             const double un = from_basis ? 0.0 : Unew[(size_t)i * n + j];
             double dn = 0.0;
 #pragma unroll
-            for (int o = 0; o < TL_MAXO; ++o) dn = fma(ci[o], cj[o], dn);
+            for (int h0 = 0; h0 < TL_BIGO; h0 += 32) {
+                if (h0 < no) {
+                    double cj[32];
+#pragma unroll
+                    for (int o = 0; o < 32; ++o) cj[o] = h0 + o < no ? sc * src[(size_t)j * n + h0 + o] : 0.0;
+#pragma unroll
+                    for (int o = 0; o < 32; ++o) dn = fma(ci[h0 + o], cj[o], dn);
+                }
+            }
             const double diff = dn - dold;
-            p1 = dn * h; p2 = dn * jj; p3 = dn * kk; p4 = diff * diff;
+            p1 = fma(dn, h, p1); p2 = fma(dn, jj, p2); p3 = fma(dn, kk, p3); p4 = fma(diff, diff, p4);
             dm[i * n + j] = dn;
             if (!from_basis) U[(size_t)i * n + j] = un;   // nobody reads U in this mode: row i of the new basis replaces the old one
         }
@@ -807,15 +1050,17 @@ extern "C" {
 void *DFT_ScfTailOpen(int nao, int nocc, unsigned long long d_hcore, unsigned long long d_overlap, unsigned long long d_basis,
                       unsigned long long d_fock_out, unsigned long long d_mo_energy)
 {
-    if (nao < 2 || nao > TL_MAXN || nocc < 1 || nocc > TL_MAXO || nocc >= nao || !d_hcore || !d_overlap || !d_basis || !d_fock_out) return nullptr;
+    if (nao < 2 || nao > TL_BIGN || nocc < 1 || nocc > TL_BIGO || nocc >= nao || !d_hcore || !d_overlap || !d_basis || !d_fock_out) return nullptr;
     TailDev *c = new (std::nothrow) TailDev();
     if (!c) return nullptr;
     const size_t n = (size_t)nao, no = (size_t)nocc, nv = n - no, n2 = n * n;
     c->n = nao; c->no = nocc;
     c->H = (const double *)d_hcore; c->S = (const double *)d_overlap;
     c->U = (double *)d_basis; c->Fx = (double *)d_fock_out; c->eig = (double *)d_mo_energy;
+    c->big = nao > TL_MAXN || nocc > TL_MAXO;
+    const size_t bigk = c->big ? nv * no : 0;
     const size_t sizes[] = {TL_SPACE * n2, TL_SPACE * n2, TL_SPACE * TL_SPACE, n * no, n * no, n * TL_SPACE, n2, n2, n2,
-                            nv * no, nv * no, nv * no, no * no, 4 * n};
+                            nv * no, nv * no, nv * no, no * no, 4 * n, bigk, c->big ? 10 * no * no : 0, bigk, bigk, bigk, bigk, bigk};
     size_t total = 0;
     for (size_t s : sizes) total += (s + 1) & ~(size_t)1;
     if (hipMalloc((void **)&c->blob, total * sizeof(double) + 256) != hipSuccess ||
@@ -828,7 +1073,8 @@ void *DFT_ScfTailOpen(int nao, int nocc, unsigned long long d_hcore, unsigned lo
         delete c;
         return nullptr;
     }
-    double **slots[] = {&c->Fb, &c->Eb, &c->Gb, &c->FC, &c->SC, &c->gpart, &c->FU, &c->A, &c->Unew, &c->Km, &c->Rm, &c->Qm, &c->Bm, &c->epart};
+    double **slots[] = {&c->Fb, &c->Eb, &c->Gb, &c->FC, &c->SC, &c->gpart, &c->FU, &c->A, &c->Unew, &c->Km, &c->Rm, &c->Qm, &c->Bm, &c->epart,
+                        &c->rden, &c->smalls, &c->Kfix, &c->KXg, &c->Kt, &c->Kt2, &c->K2};
     double *p = c->blob;
     for (size_t i = 0; i < sizeof(sizes) / sizeof(sizes[0]); ++i) {
         *slots[i] = p;
@@ -848,7 +1094,9 @@ void *DFT_ScfTailOpen(int nao, int nocc, unsigned long long d_hcore, unsigned lo
         }
         c->rot_lds = (unsigned)(off * sizeof(double));
     }
-    if (hipFuncSetAttribute((const void *)k_tail_rot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->rot_lds) != hipSuccess) {
+    if (c->big) c->rot_lds = (unsigned)(3 * (size_t)TL_BIGO * TL_BLD * sizeof(double));
+    if (hipFuncSetAttribute(c->big ? (const void *)k_tail_rot_big : (const void *)k_tail_rot, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)c->rot_lds) != hipSuccess) {
         (void)hipGetLastError();
         DFT_ScfTailClose(c);
         return nullptr;
@@ -914,11 +1162,23 @@ int DFT_ScfTailStep(void *h, int rotate, double c_hf, double tol, double canon_t
     hipLaunchKernelGGL(k_tail_err, dim3(n), dim3(128), 0, st, a, c->FC, c->SC, c->Eb, c->gpart);
     hipLaunchKernelGGL(k_tail_mix, dim3(n), dim3(128), 0, st, a, c->gpart, c->Gb, c->Fb, c->Fx, c->status);
     if (a.rotate) {
-        hipLaunchKernelGGL(k_tail_gemm, dim3(nt * nt), dim3(256), 0, st, n, n, n, c->Fx, n, 1, c->U, n, 1, c->FU, n, c->status);   // F_ext U
-        hipLaunchKernelGGL(k_tail_gemm, dim3(nt * nt), dim3(256), 0, st, n, n, n, c->U, 1, n, c->FU, n, 1, c->A, n, c->status);    // U^T (F_ext U)
-        hipLaunchKernelGGL(k_tail_rot, dim3(1), dim3(TL_ROT_T), c->rot_lds, st, a, c->lo, c->A, c->U, c->Km, c->Rm, c->Qm, c->Bm, c->FU,
-                           c->eig, c->status, (long long *)(c->status + 8));
-        hipLaunchKernelGGL(k_tail_gemm, dim3(nt * nt), dim3(256), 0, st, n, n, n, c->U, n, 1, c->FU, n, 1, c->Unew, n, c->status);   // U' = U W
+        hipLaunchKernelGGL(k_tail_gemm, dim3(nt * nt), dim3(256), 0, st, n, n, n, c->Fx, n, 1, c->U, n, 1, c->FU, n, 1.0, 0, c->status);   // F_ext U
+        hipLaunchKernelGGL(k_tail_gemm, dim3(nt * nt), dim3(256), 0, st, n, n, n, c->U, 1, n, c->FU, n, 1, c->A, n, 1.0, 0, c->status);    // U^T (F_ext U)
+        long long *stamps = (long long *)(c->status + 8);
+        if (!c->big) {
+            hipLaunchKernelGGL(k_tail_rot, dim3(1), dim3(TL_ROT_T), c->rot_lds, st, a, c->lo, c->A, c->U, c->Km, c->Rm, c->Qm, c->Bm, c->FU,
+                               c->eig, c->status, stamps);
+        } else {
+            const int no = c->no, nv = n - no, ntv = (nv + 15) / 16, nto = (no + 15) / 16;
+            double *W = c->FU;
+            hipLaunchKernelGGL(k_tail_rot_big, dim3(1), dim3(TL_ROT_T), c->rot_lds, st, a, c->A, c->Km, c->K2, c->Kt, c->Kt2, c->Qm, c->Rm, c->Bm,
+                               c->rden, c->smalls, W, c->eig, c->status, stamps, c->Kfix, c->KXg);
+            hipLaunchKernelGGL(k_tail_gemm, dim3(nto * ntv), dim3(256), 0, st, no, nv, no, c->smalls + 9 * (size_t)no * no, no, 1, c->Kfix, 1, no,
+                               W + no, n, -1.0, 0, c->status);                                         // -(1 + M X) K^T
+            hipLaunchKernelGGL(k_tail_gemm, dim3(ntv * ntv), dim3(256), 0, st, nv, nv, no, c->KXg, no, 1, c->Kfix, 1, no,
+                               W + (size_t)no * n + no, n, 1.0, 1, c->status);                         // 1 + (K X) K^T
+        }
+        hipLaunchKernelGGL(k_tail_gemm, dim3(nt * nt), dim3(256), 0, st, n, n, n, c->U, n, 1, c->FU, n, 1, c->Unew, n, 1.0, 0, c->status);   // U' = U W
     } else {
         hipLaunchKernelGGL(k_tail_need_exact, dim3(1), dim3(1), 0, st, c->status);
     }

@@ -29,6 +29,9 @@ def main(argv=None):
     p.add_argument("--device-resident", type=int, default=-1,
                    help="1: Fock build, DIIS, eigh and the density stay in HBM (only scalars cross PCIe per cycle); "
                         "0: host loop (one pinned transfer each way per cycle); -1 (default): device from 200 basis functions")
+    p.add_argument("--fused-tail", type=int, default=-1,
+                   help="1: the host part of the cycle as kernels of libdft.so (DFT_ScfTailStep; one rank, nao <= 512, nocc <= 64), "
+                        "0: the host / torch loops, -1 (default): fused where it applies")
     p.add_argument("--ao", default="resident", choices=["resident", "direct"],
                    help="resident: AO values and gradients of the whole grid stay in HBM (the reference's layout, dft.py:155,172); "
                         "direct: they are re-evaluated chunk by chunk inside every XC call (DFT_ComputeXCDirect), memory ~100 MB")
@@ -82,6 +85,7 @@ def main(argv=None):
     try:
         backend = scf.HipBackend(inp, args.functional, args.lib, quirks=bool(args.quirks), rank=rank, world=world, device=device,
                                  device_resident=None if args.device_resident < 0 else bool(args.device_resident),
+                                 fused_tail=None if args.fused_tail < 0 else bool(args.fused_tail),
                                  eigensolver=args.eigensolver, ao_mode=args.ao, xc_occ=bool(args.xc_occ))
     except Exception as e:  # dft.py:149-153
         print(e)

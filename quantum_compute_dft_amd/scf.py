@@ -408,7 +408,7 @@ class HipBackend:
         if want_tail:
             if not (world == 1 and scf_tail.supported(nao, inp.nocc)):
                 raise ValueError(f"fused_tail: one rank, nao <= {scf_tail.MAX_NAO} and nocc <= {scf_tail.MAX_NOCC} are needed")
-            if self.occ_solver is None or self.occ_solver.host is False:
+            if self.occ_solver is None:
                 self.occ_solver = OccupiedRotation(inp.S, inp.nocc, None)      # the counters the drivers report; the rotation itself runs in the kernel
             self.tail = scf_tail.ScfTail(self.solver.lib, inp.Hcore, inp.S, inp.nocc, self.dev)
         if self.device_resident or self.diis_device is not None or self.eigh.on_device:
@@ -763,17 +763,25 @@ def _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     nocc, Xh = inp.nocc, backend.eigh.Xh
     sqrt2 = float(np.sqrt(2.0))
 
-    def diagonalise_into_basis(F):                                                     # dft.py:181,227
-        e_, Cp = eigh(Xh.T @ F @ Xh, driver="evd")
-        U = Xh @ Cp
-        tail.basis.copy_(t.from_numpy(np.ascontiguousarray(U)))
+    on_dev = inp.S.shape[0] >= 400          # hipSOLVER from 400 functions, one LAPACK thread below (FockDiagonaliser)
+    Xd = t.as_tensor(Xh, dtype=t.float64, device=backend.dev) if on_dev else None
+
+    def full_solve(F_dev):                                                             # dft.py:181,227: (energies, eigenvectors on the device)
+        if on_dev:
+            e_, Cp = t.linalg.eigh(Xd.T @ F_dev @ Xd)
+            return e_.cpu().numpy(), Xd @ Cp
+        e_, Cp = eigh(Xh.T @ F_dev.cpu().numpy() @ Xh, driver="evd")
+        return e_, t.from_numpy(np.ascontiguousarray(Xh @ Cp)).to(backend.dev)
+
+    def diagonalise_into_basis(F_dev):
+        e_, U = full_solve(F_dev)
+        tail.basis.copy_(U)
         rot_stats["exact"] += 1
-        return e_, U
+        return e_
 
     tail.reset()
-    e, U = diagonalise_into_basis(inp.Hcore)
-    cocc0 = np.ascontiguousarray(sqrt2 * U[:, :nocc])
-    backend.d_cocc.copy_(t.from_numpy(cocc0)); backend.d_dm.copy_(t.from_numpy(cocc0 @ cocc0.T))   # dft.py:182
+    e = diagonalise_into_basis(tail.d_h)
+    backend.d_cocc.copy_(sqrt2 * tail.basis[:, :nocc]); backend.d_dm.copy_(backend.d_cocc @ backend.d_cocc.T)   # dft.py:182
     _log_header(log)
     E_old, xc_times, jk_times, it_times, t_start = 0.0, [], [], [], time.time()
     res = {"converged": False}
@@ -805,7 +813,7 @@ def _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
                       coef=tail.pulay_coefficients_on_host(), repeat=True)
             E_one, E_coul, E_ex, ddm, status, steps, _, _ = tail.wait()
         if status == 1:                                                                # no rotation (asked for, or possible): full solve
-            e, _ = diagonalise_into_basis(tail.fock.cpu().numpy())
+            e = diagonalise_into_basis(tail.fock)
             tail.finish(c_hf, backend.d_J, d_K, backend.d_dm, backend.d_cocc)
             E_one, E_coul, E_ex, ddm, status, _, _, _ = tail.wait()
         else:
@@ -822,9 +830,8 @@ def _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         if abs(dE) < conv_e and ddm < conv_dm:
             ok = True
             if rotate:                                                                 # as in _run_scf: the followed space against eigh(F, S)
-                e_x, Cp = eigh(Xh.T @ tail.fock.cpu().numpy() @ Xh, driver="evd")
-                C_x = Xh @ Cp
-                ok = bool(np.linalg.norm(2.0 * C_x[:, :nocc] @ C_x[:, :nocc].T - backend.d_dm.cpu().numpy()) < 1e-4)
+                e_x, C_x = full_solve(tail.fock)
+                ok = bool(float(t.linalg.norm(2.0 * C_x[:, :nocc] @ C_x[:, :nocc].T - backend.d_dm)) < 1e-4)
                 if ok:
                     e = e_x
             if ok:

@@ -7,7 +7,7 @@ import ctypes
 
 import numpy as np
 
-MAX_NAO, MAX_NOCC, SPACE = 128, 32, 8
+MAX_NAO, MAX_NOCC, SPACE = 512, 64, 8      # up to 128 x 32 the rotation's matrices live in LDS (k_tail_rot), above in memory (k_tail_rot_big)
 STATUS_DONE, STATUS_DIAGONALISE, STATUS_SINGULAR = 0, 1, 2
 
 

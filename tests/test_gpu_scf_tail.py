@@ -40,7 +40,8 @@ def _host_cycle(S, H, J, K, V, c_hf, dm, cocc, diis, rot, tol):
     return F, dn, cn, (np.sum(dn * H), 0.5 * np.sum(dn * J), -0.25 * c_hf * np.sum(dn * K) if c_hf else 0.0, np.linalg.norm(dn - dm))
 
 
-@pytest.mark.parametrize("n,no,c_hf", [(30, 7, 0.0), (114, 21, 0.0), (114, 21, 0.2), (128, 32, 0.2), (17, 1, 0.0), (45, 30, 0.2)])
+@pytest.mark.parametrize("n,no,c_hf", [(30, 7, 0.0), (114, 21, 0.0), (114, 21, 0.2), (128, 32, 0.2), (17, 1, 0.0), (45, 30, 0.2),
+                                       (150, 20, 0.2), (246, 47, 0.2), (130, 64, 0.0), (300, 33, 0.0)])   # the last four: operands in memory
 def test_tail_steps_match_the_host_classes(n, no, c_hf):
     import torch
     dev = torch.device("cuda:0")
@@ -146,17 +147,17 @@ def test_status_paths_diis_only_finish_and_singular_system():
     assert o[4] == scf_tail.STATUS_DIAGONALISE
     assert np.abs(tail.fock.cpu().numpy() - F).max() <= 1e-12 * np.abs(F).max()      # any weights summing to 1 of two equal matrices
     tail.close()
-    assert scf_tail.supported(114, 21) and not scf_tail.supported(246, 47)
+    assert scf_tail.supported(114, 21) and scf_tail.supported(494, 47) and not scf_tail.supported(1150, 250)
 
 
-@pytest.mark.parametrize("functional,eri", [("GGA", "dense"), ("B3LYP", "cholesky")])
-def test_fused_loop_matches_the_host_loop_on_benzene(functional, eri):
+@pytest.mark.parametrize("molecule,functional,eri", [("Benzene", "GGA", "dense"), ("Benzene", "B3LYP", "cholesky"), ("Anthracene", "B3LYP", "cholesky")])
+def test_fused_loop_matches_the_host_loop(molecule, functional, eri):
     """Same molecule, same thresholds (dft.py:243): the loop with its host part on the device against the host loop."""
     import torch
     from quantum_compute_dft_amd import inputs
     dev = torch.device("cuda:0")
-    inp = inputs.build("Benzene", "def2-svp", 3, device=dev, verbose=False, eri_mode=eri, chol_tol=1e-8)
-    host = scf.HipBackend(inp, functional, device=dev, device_resident=False)
+    inp = inputs.build(molecule, "def2-svp", 3, device=dev, verbose=False, eri_mode=eri, chol_tol=1e-8)
+    host = scf.HipBackend(inp, functional, device=dev, device_resident=False)      # Anthracene (246 functions, 47 occupied): the memory-resident rotation kernel
     assert host.tail is None
     r_host = scf.run_scf(inp, host, functional, log=None)
     fused = scf.HipBackend(inp, functional, device=dev)
