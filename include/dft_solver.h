@@ -213,6 +213,10 @@ void *DFT_EriColumnsOpen(int nshell, const double *shl_xyz, const int *shl_l, co
                          const int *shl_off, const int *shl_ao, const double *prim_exp, const double *prim_coef,
                          int nao, int nprim_total, const double *qmax_pairs);
 int DFT_EriColumns(void *handle, int shell_C, int shell_D, double screen, unsigned long long d_out_ptr);
+/* Several ket shell pairs in one call (their kernels run side by side): block k, laid out as DFT_EriColumns does, starts
+ * offsets[k] doubles into d_out; blocks must not overlap, [0, largest end) is cleared as a whole. */
+int DFT_EriColumnsMany(void *handle, int npairs, const int *shell_C, const int *shell_D, double screen,
+                       unsigned long long d_out_ptr, const long long *offsets);
 int DFT_EriColumnsSetStream(void *handle, unsigned long long hip_stream);
 const char *DFT_EriColumnsLastError(void *handle);
 void DFT_EriColumnsClose(void *handle);

@@ -56,35 +56,59 @@ def _cholesky_eri_device(shells, tol, span, max_vectors, screen, verbose, device
         if dcols is None:
             stage = torch.empty((maxq, n2), dtype=torch.float64).pin_memory()    # the host engine writes the columns here
             stage_np = stage.numpy()
-        else:
-            dstage = torch.empty((maxq, n2), dtype=torch.float64, device=dev)    # ... or the device kernel, here
         k = 0
         screen = tol * 1e-4 if screen is None else screen
+        # Several shell-pair blocks per step with the device columns: the blocks whose largest residual diagonal is within
+        # `batch_frac` of the step's pivot (at most `batch`) are computed side by side (DFT_EriColumnsMany), take ONE residual
+        # GEMM and ONE small pivoted factorisation on the host together -- the per-step host work (a sync, the pivots of the
+        # block, the index tensors: 3 of the 5 s of an Anthracene/def2-TZVP factorisation, one block per step) is shared by
+        # them.  Still a pivoted Cholesky with the same residual bound; the pivot ORDER differs from the one-block sequence.
+        import os
+        batch = int(os.environ.get("QCDFT_CHOL_BATCH", "8")) if dcols is not None else 1      # (the environment: tools/chol_dev_time.py's sweeps)
+        batch_frac = float(os.environ.get("QCDFT_CHOL_FRAC", "0.1"))
+        nsh = shells.nshell
+        so = torch.as_tensor(shell_of, device=dev)
+        hi, lo = torch.maximum(so[:, None], so[None, :]), torch.minimum(so[:, None], so[None, :])
+        blk = (hi * nsh + lo).reshape(-1)                              # shell-pair block of every (i, j), (C, D) and (D, C) as one
+        if dcols is not None:
+            dstage = torch.empty((batch * maxq, n2), dtype=torch.float64, device=dev)
         while k < cap_max:
-            dmax, p = torch.max(diag, dim=0)
-            dmax, p = float(dmax), int(p)
-            if dmax < tol:
-                break
-            C, D = int(shell_of[p // n]), int(shell_of[p % n])
-            c0, d0 = int(shells.ao[C]), int(shells.ao[D])
-            nc, nd = 2 * int(shells.l[C]) + 1, 2 * int(shells.l[D]) + 1
-            nq = nc * nd
-            qidx_h = ((c0 + np.arange(nc))[:, None] * n + (d0 + np.arange(nd))[None, :]).reshape(-1)
+            if batch > 1:
+                pm = torch.zeros(nsh * nsh, dtype=torch.float64, device=dev).scatter_reduce(0, blk, diag, "amax", include_self=True)
+                vals, ids = torch.topk(pm, min(batch, pm.numel()))
+                vals, ids = vals.cpu().numpy(), ids.cpu().numpy()
+                dmax = float(vals[0])
+                if dmax < tol:
+                    break
+                pairs = [(int(b) // nsh, int(b) % nsh) for v, b in zip(vals, ids) if v >= max(tol, batch_frac * dmax)]
+            else:
+                dmax, p = torch.max(diag, dim=0)
+                dmax, p = float(dmax), int(p)
+                if dmax < tol:
+                    break
+                pairs = [(int(shell_of[p // n]), int(shell_of[p % n]))]
+            qs = []
+            for C, D in pairs:
+                c0, d0 = int(shells.ao[C]), int(shells.ao[D])
+                nc, nd = 2 * int(shells.l[C]) + 1, 2 * int(shells.l[D]) + 1
+                qs.append(((c0 + np.arange(nc))[:, None] * n + (d0 + np.arange(nd))[None, :]).reshape(-1))
+            qidx_h = np.concatenate(qs)
+            nq = len(qidx_h)
             qidx = torch.as_tensor(qidx_h, device=dev)
             if dcols is None:
+                C, D = pairs[0]
                 eri.cols(C, D, screen, out=stage_np[:nq], lower_only=True)     # the host writes i >= j only (integrals.c)
                 low = stage[:nq].to(dev, non_blocking=True).view(nq, n, n)
             else:
-                low = dcols.cols(C, D, screen, dstage)                         # the same, computed in HBM
+                low = dcols.cols_many(pairs, screen, dstage)                   # the same, computed in HBM
             res = (torch.tril(low) + torch.tril(low, -1).transpose(1, 2)).reshape(nq, n2)   # ... and the device mirrors
             if k:
                 res -= L[:k, qidx].T @ L[:k]
             floor = max(tol, span * dmax)
-            # The block's vectors in ONE step.  The sequential loop (pick the largest residual diagonal of the block, divide
+            # The step's vectors in ONE go.  The sequential loop (pick the largest residual diagonal of the block, divide
             # its column, subtract the rank-1 term from the block's columns, repeat) is a pivoted Cholesky of the block's own
-            # nq x nq residual A = res[:, qidx]: that small matrix goes to the host once (one sync per block instead of one
-            # per vector: 722 against 4874 at Anthracene/def2-TZVP), the pivots B and the triangular factor G with
-            # A[B, B] = G G^T come from it, and the vectors are V = G^-1 res[B] -- one triangular solve on the device.
+            # nq x nq residual A = res[:, qidx]: that small matrix goes to the host once, the pivots B and the triangular
+            # factor G with A[B, B] = G G^T come from it, and the vectors are V = G^-1 res[B].
             A = res[:, qidx].cpu().numpy()
             B, G = _block_pivots(A, floor, cap_max - k)
             r = len(B)
@@ -93,11 +117,16 @@ def _cholesky_eri_device(shells, tol, span, max_vectors, screen, verbose, device
                     cap = min(cap_max, max(2 * cap, k + r))
                     L = torch.cat([L, torch.empty((cap - L.shape[0], n2), dtype=torch.float64, device=dev)])
                 Bt = torch.as_tensor(np.asarray(B), device=dev)
-                V = torch.linalg.solve_triangular(torch.as_tensor(G, device=dev), res[Bt], upper=False)
+                # V = G^-1 res[B]: the small triangular inverse on the host (r <= a few hundred), one GEMM on the device
+                # (rocBLAS's trsm wants a workspace it could not get for r x nao^2 right-hand sides above r ~ 100)
+                from scipy.linalg import solve_triangular
+                Ginv = solve_triangular(G, np.eye(r), lower=True)
+                V = torch.as_tensor(Ginv, device=dev) @ res[Bt]
                 L[k:k + r] = V
                 k += r
                 diag -= (V * V).sum(0)
                 diag[qidx[Bt]] = 0.0
+                diag[(qidx[Bt] % n) * n + qidx[Bt] // n] = 0.0     # the mirrored index (j, i) of every pivot (i, j)
             diag.clamp_(min=0.0)
             if verbose:
                 print(f"cholesky: {k} vectors, residual {float(diag.max()):.3e}", flush=True)

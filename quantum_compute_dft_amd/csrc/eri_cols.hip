@@ -459,25 +459,15 @@ int DFT_EriColumnsSetStream(void *h, unsigned long long hip_stream)
 
 const char *DFT_EriColumnsLastError(void *h) { return h ? ((EriDev *)h)->err : "null handle"; }
 
-int DFT_EriColumns(void *h, int C, int D, double screen, unsigned long long d_out)
+} // extern "C"
+
+// The launches of one ket shell pair into `out` (already cleared), dealt to the side streams from launch counter `nlaunch` on.
+static int launch_pair(EriDev *c, int C, int D, double screen, double *out, int &nlaunch)
 {
-    EriDev *c = (EriDev *)h;
-    if (!c || C < 0 || D < 0 || C >= c->nshell || D >= c->nshell || !d_out) return -1;
-    c->err[0] = 0;
     const int swap = C < D, Cs = swap ? D : C, Ds = swap ? C : D; // stored pair (max, min)
     const int kcd = Cs * (Cs + 1) / 2 + Ds;
     const int lc = c->h_ls[Cs], ld = c->h_ls[Ds];
     const int ncdc = (lc + 1) * (lc + 2) / 2 * ((ld + 1) * (ld + 2) / 2);
-    const size_t nq = (size_t)(2 * lc + 1) * (2 * ld + 1);
-    double *out = (double *)d_out;
-    if (hipMemsetAsync(out, 0, sizeof(double) * nq * c->nao * c->nao, c->stream) != hipSuccess) {
-        snprintf(c->err, sizeof c->err, "memset of the column block failed");
-        return -1;
-    }
-    // fork: the side streams start behind the clear (and whatever the caller queued before it on the handle's stream)
-    (void)hipEventRecord(c->fork, c->stream);
-    for (int i = 0; i < 4; ++i) (void)hipStreamWaitEvent(c->side[i], c->fork, 0);
-    int nlaunch = 0;
     const int mtk = max_terms(lc, ld);
     for (int la = 0; la < 4; ++la)
         for (int lb = 0; lb <= la; ++lb) {
@@ -530,6 +520,29 @@ int DFT_EriColumns(void *h, int C, int D, double screen, unsigned long long d_ou
 #undef QC_ERI_LAUNCH
             }
         }
+    return 0;
+}
+
+static int columns_many(EriDev *c, int npairs, const int *Cs, const int *Ds, double screen, double *out, const long long *offsets)
+{
+    c->err[0] = 0;
+    size_t total = 0;
+    for (int k = 0; k < npairs; ++k) {
+        if (Cs[k] < 0 || Ds[k] < 0 || Cs[k] >= c->nshell || Ds[k] >= c->nshell) return -1;
+        const size_t nq = (size_t)(2 * c->h_ls[Cs[k]] + 1) * (2 * c->h_ls[Ds[k]] + 1);
+        if (offsets[k] < 0) return -1;
+        total = std::max(total, (size_t)offsets[k] + nq * c->nao * c->nao);
+    }
+    if (hipMemsetAsync(out, 0, sizeof(double) * total, c->stream) != hipSuccess) {
+        snprintf(c->err, sizeof c->err, "memset of the column block failed");
+        return -1;
+    }
+    // fork: the side streams start behind the clear (and whatever the caller queued before it on the handle's stream)
+    (void)hipEventRecord(c->fork, c->stream);
+    for (int i = 0; i < 4; ++i) (void)hipStreamWaitEvent(c->side[i], c->fork, 0);
+    int nlaunch = 0;
+    for (int k = 0; k < npairs; ++k)
+        if (launch_pair(c, Cs[k], Ds[k], screen, out + offsets[k], nlaunch) != 0) return -1;
     for (int i = 0; i < 4; ++i) { // join: the handle's stream continues behind all of them
         (void)hipEventRecord(c->join[i], c->side[i]);
         (void)hipStreamWaitEvent(c->stream, c->join[i], 0);
@@ -540,6 +553,26 @@ int DFT_EriColumns(void *h, int C, int D, double screen, unsigned long long d_ou
         return -1;
     }
     return 0;
+}
+
+extern "C" {
+
+int DFT_EriColumns(void *h, int C, int D, double screen, unsigned long long d_out)
+{
+    EriDev *c = (EriDev *)h;
+    if (!c || !d_out) return -1;
+    const long long zero = 0;
+    return columns_many(c, 1, &C, &D, screen, (double *)d_out, &zero);
+}
+
+// Several ket shell pairs in one call: block k (as DFT_EriColumns lays it out) starts offsets[k] doubles into d_out; the
+// blocks must not overlap and [0, max end) is cleared as a whole.  One fork / join around all launches: the pairs' kernels
+// run side by side instead of pair after pair.
+int DFT_EriColumnsMany(void *h, int npairs, const int *C, const int *D, double screen, unsigned long long d_out, const long long *offsets)
+{
+    EriDev *c = (EriDev *)h;
+    if (!c || !d_out || npairs <= 0 || !C || !D || !offsets) return -1;
+    return columns_many(c, npairs, C, D, screen, (double *)d_out, offsets);
 }
 
 } // extern "C"

@@ -180,6 +180,8 @@ class DeviceEriColumns:
         L.DFT_EriColumnsOpen.restype = ctypes.c_void_p
         L.DFT_EriColumns.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_uint64]
         L.DFT_EriColumns.restype = ctypes.c_int
+        L.DFT_EriColumnsMany.argtypes = [ctypes.c_void_p, ctypes.c_int, ip, ip, ctypes.c_double, ctypes.c_uint64, ctypes.POINTER(ctypes.c_longlong)]
+        L.DFT_EriColumnsMany.restype = ctypes.c_int
         L.DFT_EriColumnsLastError.argtypes = [ctypes.c_void_p]
         L.DFT_EriColumnsLastError.restype = ctypes.c_char_p
         L.DFT_EriColumnsClose.argtypes = [ctypes.c_void_p]
@@ -207,3 +209,18 @@ class DeviceEriColumns:
         if self.lib.DFT_EriColumns(self._h, int(C), int(D), float(screen), ctypes.c_uint64(out.data_ptr())) != 0:
             raise RuntimeError("libdft: " + (self.lib.DFT_EriColumnsLastError(self._h) or b"").decode())
         return out.view(-1)[:nq * self.nao * self.nao].view(nq, self.nao, self.nao)
+
+    def cols_many(self, pairs, screen, out):
+        """The blocks of several ket shell pairs [(C, D), ...] back to back in `out` (their kernels run side by side on the
+        device); returns `out` viewed as (sum of the blocks' rows, nao, nao)."""
+        n2 = self.nao * self.nao
+        nqs = [(2 * int(self.shells.l[C]) + 1) * (2 * int(self.shells.l[D]) + 1) for C, D in pairs]
+        offs = np.concatenate([[0], np.cumsum(nqs)[:-1]]).astype(np.int64) * n2
+        tot = int(sum(nqs))
+        assert out.is_cuda and out.is_contiguous() and out.numel() >= tot * n2
+        Cs = (ctypes.c_int * len(pairs))(*[int(C) for C, _ in pairs]); Ds = (ctypes.c_int * len(pairs))(*[int(D) for _, D in pairs])
+        of = (ctypes.c_longlong * len(pairs))(*[int(x) for x in offs])
+        if self.lib.DFT_EriColumnsMany(self._h, len(pairs), Cs, Ds, float(screen), ctypes.c_uint64(out.data_ptr()), of) != 0:
+            raise RuntimeError("libdft: " + (self.lib.DFT_EriColumnsLastError(self._h) or b"").decode())
+        return out.view(-1)[:tot * n2].view(tot, self.nao, self.nao)
+
