@@ -403,14 +403,18 @@ class HipBackend:
         # None = auto (one rank, `device_resident` not forced off); the host and torch loops remain for everything else.
         from . import scf_tail
         self.tail = None
-        want_tail = (world == 1 and self.occ_solver is not None and device_resident is not False and ao_mode == "resident"
+        # With several ranks rank 0 alone runs the tail (it is authoritative for the replicated state, grid_shard.ReplicaSync) and
+        # [dm | cocc | scalars] go out in one broadcast; `self.fused` tells every rank to walk that loop.
+        want_tail = (self.occ_solver is not None and device_resident is not False and ao_mode == "resident"
                      and scf_tail.supported(nao, inp.nocc)) if fused_tail is None else bool(fused_tail)
+        self.fused = bool(want_tail)
         if want_tail:
-            if not (world == 1 and scf_tail.supported(nao, inp.nocc)):
-                raise ValueError(f"fused_tail: one rank, nao <= {scf_tail.MAX_NAO} and nocc <= {scf_tail.MAX_NOCC} are needed")
+            if not scf_tail.supported(nao, inp.nocc) or ao_mode != "resident":
+                raise ValueError(f"fused_tail: resident AO planes, nao <= {scf_tail.MAX_NAO} and nocc <= {scf_tail.MAX_NOCC} are needed")
             if self.occ_solver is None:
                 self.occ_solver = OccupiedRotation(inp.S, inp.nocc, None)      # the counters the drivers report; the rotation itself runs in the kernel
-            self.tail = scf_tail.ScfTail(self.solver.lib, inp.Hcore, inp.S, inp.nocc, self.dev)
+            if rank == 0:
+                self.tail = scf_tail.ScfTail(self.solver.lib, inp.Hcore, inp.S, inp.nocc, self.dev)
         if self.device_resident or self.diis_device is not None or self.eigh.on_device:
             # rocBLAS / hipSOLVER load their code objects and create their handles on first use (~0.1-0.3 s in all):
             # done here, on operands of the run's own shapes, so that it is booked as initialisation -- where the
@@ -512,7 +516,7 @@ def run_scf(inp, backend, functional, max_cycle=200, conv_e=1e-8, conv_dm=1e-6, 
     # functions one thread is fastest for everything left on the host (dsyevd at n = 114: 0.67 ms on one
     # thread, 0.87 on 16), above it the pool gets the CPU share
     with blas_threads(1 if inp.S.shape[0] < 400 else None):
-        if getattr(backend, "tail", None) is not None:
+        if getattr(backend, "fused", False):
             return _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log)
         if getattr(backend, "device_resident", False):
             return _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log)
@@ -751,20 +755,22 @@ def _run_scf_device(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
 
 
 def _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
-    """The loop with its host part on the device (scf_tail.ScfTail): per cycle the J / K and XC kernels, then six launches for
-    dft.py:212-236, then ONE wait on host-mapped memory for the four energy / convergence scalars.  The few full
-    diagonalisations of a run (first cycle, refused rotations, the final aufbau check) are LAPACK calls on the host,
-    as in the other two loops at this size."""
+    """The loop with its host part on the device (scf_tail.ScfTail): per cycle the J / K and XC kernels, then the tail's
+    launches for dft.py:212-236, then ONE wait on host-mapped memory for the energy / convergence scalars.  The few full
+    diagonalisations of a run (first cycle, refused rotations, the final aufbau check) are LAPACK calls on the host below
+    400 functions and hipSOLVER above, as in the other two loops.  With several ranks the cycle's device work is the sharded
+    one (grid_shard.ShardedFock: local sweep + local J/K + one all-reduce), rank 0 alone runs the tail, and
+    [dm | cocc | scalars] reach the other ranks in one broadcast."""
     t = backend.torch
     tail, rot_stats = backend.tail, backend.occ_solver.stats
+    root, sync, world = backend.rank == 0, backend.replica_sync, backend.world
     functional = functional.upper()
     c_hf = 0.2 if functional == "B3LYP" else 0.0
     want_k = functional == "B3LYP"
     nocc, Xh = inp.nocc, backend.eigh.Xh
     sqrt2 = float(np.sqrt(2.0))
-
     on_dev = inp.S.shape[0] >= 400          # hipSOLVER from 400 functions, one LAPACK thread below (FockDiagonaliser)
-    Xd = t.as_tensor(Xh, dtype=t.float64, device=backend.dev) if on_dev else None
+    Xd = t.as_tensor(Xh, dtype=t.float64, device=backend.dev) if (on_dev and root) else None
 
     def full_solve(F_dev):                                                             # dft.py:181,227: (energies, eigenvectors on the device)
         if on_dev:
@@ -779,9 +785,14 @@ def _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         rot_stats["exact"] += 1
         return e_
 
-    tail.reset()
-    e = diagonalise_into_basis(tail.d_h)
-    backend.d_cocc.copy_(sqrt2 * tail.basis[:, :nocc]); backend.d_dm.copy_(backend.d_cocc @ backend.d_cocc.T)   # dft.py:182
+    e = None
+    if root:
+        tail.reset()
+        e = diagonalise_into_basis(tail.d_h)
+        backend.d_cocc.copy_(sqrt2 * tail.basis[:, :nocc]); backend.d_dm.copy_(backend.d_cocc @ backend.d_cocc.T)   # dft.py:182
+    scal = t.zeros(8, dtype=t.float64, device=backend.dev)                           # what travels with [dm | cocc] when there are replicas
+    if sync:
+        sync.broadcast([backend._up])                                                  # [dm | cocc] is one flat buffer (HipBackend)
     _log_header(log)
     E_old, xc_times, jk_times, it_times, t_start = 0.0, [], [], [], time.time()
     res = {"converged": False}
@@ -792,34 +803,47 @@ def _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     sol = backend.solver
     for cycle in range(max_cycle):
         t_it = time.time()
-        # the whole cycle is queued without a host wait in between: J/K, the sweep (Exc stays on the device), the tail
-        ev = [t.cuda.Event(enable_timing=True) for _ in range(3)]
-        ev[0].record()
-        backend._jk_device(want_k)
-        ev[1].record()
-        if backend.xc_occ:
-            sol.compute_xc_occ_async(backend.ngrid, backend.nao, nocc, backend.d_cocc, backend.d_ao, backend.d_w, backend.d_v, d_exc,
-                                     backend.d_gr, backend.d_dm)
+        if world == 1:
+            # the whole cycle is queued without a host wait in between: J/K, the sweep (Exc stays on the device), the tail
+            ev = [t.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+            backend._jk_device(want_k)
+            ev[1].record()
+            if backend.xc_occ:
+                sol.compute_xc_occ_async(backend.ngrid, backend.nao, nocc, backend.d_cocc, backend.d_ao, backend.d_w, backend.d_v, d_exc,
+                                         backend.d_gr, backend.d_dm)
+            else:
+                sol.compute_xc_async(backend.ngrid, backend.nao, backend.d_dm, backend.d_ao, backend.d_w, backend.d_v, d_exc, backend.d_gr)
+            ev[2].record()
+            marks.append(ev)
+            E_xc = None
         else:
-            sol.compute_xc_async(backend.ngrid, backend.nao, backend.d_dm, backend.d_ao, backend.d_w, backend.d_v, d_exc, backend.d_gr)
-        ev[2].record()
-        marks.append(ev)
-        tol = 1e-10 if last_ddm is None else min(max(1e-10, 1e-3 * last_ddm), 1e-5)    # as OccupiedRotation.occupied(accuracy)
-        tail.step(rotate, c_hf, tol, backend.d_J, d_K, backend.d_v, backend.d_dm, backend.d_cocc, d_exc=d_exc)
-        E_one, E_coul, E_ex, ddm, status, steps, sweeps, E_xc = tail.wait()
-        tail_log.append((status, steps, sweeps))
-        if status == 2:                                                                # singular Pulay system: least squares on the host
-            tail.step(rotate, c_hf, tol, backend.d_J, d_K, backend.d_v, backend.d_dm, backend.d_cocc,
-                      coef=tail.pulay_coefficients_on_host(), repeat=True)
-            E_one, E_coul, E_ex, ddm, status, steps, _, _ = tail.wait()
-        if status == 1:                                                                # no rotation (asked for, or possible): full solve
-            e = diagonalise_into_basis(tail.fock)
-            tail.finish(c_hf, backend.d_J, d_K, backend.d_dm, backend.d_cocc)
-            E_one, E_coul, E_ex, ddm, status, _, _, _ = tail.wait()
-        else:
-            rot_stats["rotated"] += 1; rot_stats["inner_steps"] += steps
-        if status != 0:
-            raise RuntimeError(f"SCF tail: status {status}")
+            E_xc, t_xc = backend._device_parts(want_k)                                 # sharded: ends in the all-reduce of [Vxc | J | K | Exc]
+            xc_times.append(t_xc); jk_times.append(time.time() - t_it - t_xc)
+        if root:
+            tol = 1e-10 if last_ddm is None else min(max(1e-10, 1e-3 * last_ddm), 1e-5)    # as OccupiedRotation.occupied(accuracy)
+            tail.step(rotate, c_hf, tol, backend.d_J, d_K, backend.d_v, backend.d_dm, backend.d_cocc, d_exc=d_exc if world == 1 else None)
+            E_one, E_coul, E_ex, ddm, status, steps, sweeps, exc_dev = tail.wait()
+            tail_log.append((status, steps, sweeps))
+            if status == 2:                                                            # singular Pulay system: least squares on the host
+                tail.step(rotate, c_hf, tol, backend.d_J, d_K, backend.d_v, backend.d_dm, backend.d_cocc,
+                          coef=tail.pulay_coefficients_on_host(), repeat=True)
+                E_one, E_coul, E_ex, ddm, status, steps, _, _ = tail.wait()
+            if status == 1:                                                            # no rotation (asked for, or possible): full solve
+                e = diagonalise_into_basis(tail.fock)
+                tail.finish(c_hf, backend.d_J, d_K, backend.d_dm, backend.d_cocc)
+                E_one, E_coul, E_ex, ddm, status, _, _, _ = tail.wait()
+            else:
+                rot_stats["rotated"] += 1; rot_stats["inner_steps"] += steps
+            if status != 0:
+                raise RuntimeError(f"SCF tail: status {status}")
+            if world == 1:
+                E_xc = exc_dev
+        if sync:
+            if root:
+                scal[:4] = t.tensor([E_one, E_coul, E_ex, ddm], dtype=t.float64)
+            sync.broadcast([backend._up, scal])
+            E_one, E_coul, E_ex, ddm = scal[:4].tolist()
         last_ddm = ddm
         E_tot = E_one + E_coul + E_xc + E_ex + inp.E_nuc
         dE = E_tot - E_old
@@ -827,23 +851,27 @@ def _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
         if log:
             log(f"{cycle + 1:4d} {E_tot:18.8f} {dE:15.6e} {ddm:15.6e} {E_ex:12.6f}")
         res.update(E_tot=E_tot, E_one=E_one, E_coul=E_coul, E_xc=E_xc, E_ex_hf=E_ex, cycles=cycle + 1)
-        if abs(dE) < conv_e and ddm < conv_dm:
-            ok = True
+        if abs(dE) < conv_e and ddm < conv_dm:                                         # the same scalars on every rank
+            ok = t.ones(1, dtype=t.float64, device=backend.dev)
             if rotate:                                                                 # as in _run_scf: the followed space against eigh(F, S)
-                e_x, C_x = full_solve(tail.fock)
-                ok = bool(float(t.linalg.norm(2.0 * C_x[:, :nocc] @ C_x[:, :nocc].T - backend.d_dm)) < 1e-4)
-                if ok:
-                    e = e_x
-            if ok:
+                if root:
+                    e_x, C_x = full_solve(tail.fock)
+                    ok[0] = float(float(t.linalg.norm(2.0 * C_x[:, :nocc] @ C_x[:, :nocc].T - backend.d_dm)) < 1e-4)
+                    if float(ok[0]):
+                        e = e_x
+                if sync:
+                    sync.broadcast([ok])
+            if float(ok[0]):
                 res["converged"] = True
                 break
             rotate = False
-            tail.reset()
+            if root:
+                tail.reset()
             if log:
                 log("     converged occupied space is not the aufbau one: continuing with eigh(F, S) every cycle")
         E_old = E_tot
     res["dm"] = backend.d_dm.cpu().numpy()
-    res["mo_energy"] = np.asarray(e)
+    res["mo_energy"] = None if e is None else np.asarray(e)
     res["loop"] = "fused"
     res["tail_log"] = tail_log
     for ev in marks:                                                                   # device-side durations: nothing waited in between

@@ -37,7 +37,9 @@ def _rank_main(rank, world, port, fn, eri_mode, out_dir, device_resident=False, 
 
 @pytest.mark.parametrize("fn,eri_mode,device_resident,eigensolver", [
     ("B3LYP", "cholesky", False, "auto"), ("GGA", "dense", False, "auto"), ("B3LYP", "dense", False, "auto"),
-    ("B3LYP", "cholesky", True, "auto"), ("GGA", "cholesky", True, "rotate"), ("B3LYP", "dense", False, "rotate")])
+    ("B3LYP", "cholesky", True, "auto"), ("GGA", "cholesky", True, "rotate"), ("B3LYP", "dense", False, "rotate"),
+    # rank 0 runs the SCF tail kernels (scf._run_scf_fused with replicas), the others receive [dm | cocc | scalars]
+    ("B3LYP", "cholesky", None, "rotate"), ("GGA", "dense", None, "rotate")])
 def test_two_ranks_on_one_gpu_match_the_single_rank_scf(tmp_path, fn, eri_mode, device_resident, eigensolver):
     import torch.multiprocessing as mp
     from quantum_compute_dft_amd import inputs, scf
