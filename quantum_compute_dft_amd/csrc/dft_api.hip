@@ -210,7 +210,7 @@ int auto_ksplit(const XCSolver *s, long ngrid, int nblk)
 // pays (xc_occ_kernels.hpp); `dm` may then be null.
 bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *ao,
               const double *ao_grad, const double *w, double *vxc, bool want_host_exc,
-              const double *cocc = nullptr, int nocc = 0)
+              const double *cocc = nullptr, int nocc = 0, double *exc_out = nullptr)
 {
     s->last_error.clear();
     s->n_timed = 0;
@@ -308,7 +308,7 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     double *Dp = (double *)s->dsym.p, *rho = (double *)s->rho.p, *sigma = (double *)s->sigma.p,
            *grad = (double *)s->grad.p, *coef = (double *)s->coef.p,
            *partial = (double *)s->partial.p, *slabs = (double *)s->slabs.p,
-           *exc = (double *)s->exc.p;
+           *exc = exc_out ? exc_out : (double *)s->exc.p;   // the asynchronous entries' caller-owned scalar: written by the finishing kernel itself
     const double *gx = ao_grad, *gy = gga ? ao_grad + ng * nao : nullptr,
                  *gz = gga ? ao_grad + 2 * ng * nao : nullptr;
     hipStream_t st = s->stream;
@@ -947,9 +947,7 @@ int DFT_ComputeXCOccAsync(XCSolver *s, long long ngrid, int nao, int nocc, unsig
     DeviceGuard dg(s);
     if (!d_cocc) { set_error(s, "DFT_ComputeXCOccAsync needs the occupied orbitals"); return -1; }
     if (!xc_sweep(s, (long)ngrid, nao, (const double *)d_dm, (const double *)d_ao,
-                  (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc, false, (const double *)d_cocc, nocc))
-        return -1;
-    if (d_exc && !hip_ok(s, hipMemcpyAsync((void *)d_exc, s->exc.p, sizeof(double), hipMemcpyDeviceToDevice, s->stream), "copy Exc"))
+                  (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc, false, (const double *)d_cocc, nocc, (double *)d_exc))
         return -1;
     return 0;
 }
@@ -969,9 +967,7 @@ int DFT_ComputeXCAsync(XCSolver *s, long long ngrid, int nao, unsigned long long
     if (!s) return -1;
     DeviceGuard dg(s);
     if (!xc_sweep(s, (long)ngrid, nao, (const double *)d_dm, (const double *)d_ao,
-                  (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc, false))
-        return -1;
-    if (d_exc && !hip_ok(s, hipMemcpyAsync((void *)d_exc, s->exc.p, sizeof(double), hipMemcpyDeviceToDevice, s->stream), "copy Exc"))
+                  (const double *)d_ao_grad, (const double *)d_w, (double *)d_vxc, false, nullptr, 0, (double *)d_exc))
         return -1;
     return 0;
 }

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_tail_fock(TailArgs a, const double *__r
                                                    double *__restrict__ Fb, double *__restrict__ FC, double *__restrict__ SC,
                                                    int *__restrict__ status)
 {
-    __shared__ double frow[TL_BIGN], srow[TL_BIGN], pf[4][TL_BIGO], ps[4][TL_BIGO];
+    __shared__ double frow[TL_BIGN], srow[TL_BIGN], pf[8][TL_BIGO], ps[8][TL_BIGO];
     const int n = a.n, no = a.no, i = blockIdx.x, t = threadIdx.x;
     if (i == 0 && t == 0) { status[0] = 0; status[1] = 0; status[2] = 0; }   // read by the kernels behind this one only
     double *F = Fb + (size_t)a.slot * n * n;
@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256) void k_tail_fock(TailArgs a, const double *__r
         srow[j] = S[i * n + j];
     }
     __syncthreads();
-    const int o = t & 63, q = t >> 6, per = (n + 3) >> 2, j0 = q * per, j1 = min(n, j0 + per);
+    // eight j ranges of 32 orbitals, or four of 64
+    const bool wide = no > 32;
+    const int o = wide ? t & 63 : t & 31, q = wide ? t >> 6 : t >> 5, nq = wide ? 4 : 8;
+    const int per = (n + nq - 1) / nq, j0 = q * per, j1 = min(n, j0 + per);
     double fc = 0.0, sc = 0.0;
     if (o < no)
         for (int j = j0; j < j1; ++j) {
@@ -119,8 +122,10 @@ __global__ __launch_bounds__(256) void k_tail_fock(TailArgs a, const double *__r
     ps[q][o] = sc;
     __syncthreads();
     if (t < no) {
-        FC[i * no + t] = (pf[0][t] + pf[1][t]) + (pf[2][t] + pf[3][t]);
-        SC[i * no + t] = (ps[0][t] + ps[1][t]) + (ps[2][t] + ps[3][t]);
+        double x = (pf[0][t] + pf[1][t]) + (pf[2][t] + pf[3][t]), y = (ps[0][t] + ps[1][t]) + (ps[2][t] + ps[3][t]);
+        if (!wide) { x += (pf[4][t] + pf[5][t]) + (pf[6][t] + pf[7][t]); y += (ps[4][t] + ps[5][t]) + (ps[6][t] + ps[7][t]); }
+        FC[i * no + t] = x;
+        SC[i * no + t] = y;
     }
 }
 

@@ -801,11 +801,12 @@ def _run_scf_fused(inp, backend, functional, max_cycle, conv_e, conv_dm, log):
     d_exc = t.zeros(1, dtype=t.float64, device=backend.dev)
     marks, tail_log = [], []                                                           # (start, J/K done, XC done) events; (status, fixed-point steps, Jacobi sweeps)
     sol = backend.solver
+    pool = [t.cuda.Event(enable_timing=True) for _ in range(3 * 40)] if world == 1 else []   # made here: not in the cycles' time
     for cycle in range(max_cycle):
         t_it = time.time()
         if world == 1:
             # the whole cycle is queued without a host wait in between: J/K, the sweep (Exc stays on the device), the tail
-            ev = [t.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev = pool[3 * cycle:3 * cycle + 3] if 3 * cycle + 3 <= len(pool) else [t.cuda.Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
             backend._jk_device(want_k)
             ev[1].record()
