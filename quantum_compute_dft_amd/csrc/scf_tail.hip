@@ -433,53 +433,48 @@ __device__ __forceinline__ double half_sum(double v)
     return bcast(v, 0) + bcast(v, 16);
 }
 
-// Cholesky P = L L^T in the registers of wave 0 (lane i holds row i; the trailing update takes L[k][j] from lane k),
-// then L^-1 (wave 0) and (1 + L)^-1 (wave 1), one column per lane by forward substitution.
+// Cholesky P = L L^T (P = 1 + Pm symmetrised) by wave 0, left-looking, in LDS: lane i owns row i and subtracts
+// sum_k<j L[i][k] L[j][k] from P[i][j] (row j is read by every lane at the same address: a broadcast); then L^-1 (wave 0) and
+// (1 + L)^-1 (wave 1) by forward substitution, a column per lane.  Plain loops: the fully unrolled register form of this
+// (32 x 32 / 2 steps with v_readlane broadcasts) ran 2.5x longer, on instruction fetch.  Rows and columns past n_occ: identity.
 template <int MAXO>
 __device__ __forceinline__ void chol_and_inverses(int no, const double *Pm, double (*Lm)[MAXO + 1], double (*Li)[MAXO + 1], double (*L1)[MAXO + 1])
 {
     const int t = threadIdx.x;
+    for (int e = t; e < MAXO * MAXO; e += blockDim.x) {
+        const int i = e / MAXO, j = e - i * MAXO;
+        Lm[i][j] = (i < no && j < no) ? 0.5 * (Pm[i * no + j] + Pm[j * no + i]) + (i == j ? 1.0 : 0.0) : (i == j ? 1.0 : 0.0);
+        Li[i][j] = 0.0;
+        L1[i][j] = 0.0;
+    }
+    __syncthreads();
     if (t < 64) {
-        const int lane = t;
-        double r[MAXO];
-#pragma unroll
-        for (int j = 0; j < MAXO; ++j)
-            r[j] = (lane < no && j < no) ? 0.5 * (Pm[lane * no + j] + Pm[j * no + lane]) + (lane == j ? 1.0 : 0.0) : (lane == j ? 1.0 : 0.0);
-#pragma unroll
-        for (int j = 0; j < MAXO; ++j) {
-            if (j < no) {
-                const double djj = sqrt(bcast(r[j], j));
-                r[j] = lane == j ? djj : (lane > j ? r[j] / djj : 0.0);
-#pragma unroll
-                for (int k = j + 1; k < MAXO; ++k)
-                    if (k < no) r[k] -= r[j] * bcast(r[j], k);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        const int lane = t, row = lane < MAXO ? lane : MAXO - 1;
+        for (int j = 0; j < no; ++j) {
+            double s = Lm[row][j];
+            for (int k = 0; k < j; ++k) s -= Lm[row][k] * Lm[j][k];
+            const double djj = sqrt(bcast(s, j));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every lane has read column j's inputs
+            if (lane == j) Lm[j][j] = djj;
+            else if (lane > j && lane < no) Lm[lane][j] = s / djj;
+            else if (lane < j) Lm[lane][j] = 0.0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and sees column j before the next one (one wave: LDS in order)
         }
-#pragma unroll
-        for (int j = 0; j < MAXO; ++j)
-            if (lane < MAXO) Lm[lane][j] = j <= lane ? r[j] : 0.0;
     }
     __syncthreads();
     if (t < 128) {
-        const int lane = t & 63;
-        const bool plus = t >= 64;
-        double x[MAXO];
-#pragma unroll
-        for (int i = 0; i < MAXO; ++i) {
-            double s = lane == i ? 1.0 : 0.0;
-            x[i] = lane == i ? 1.0 : 0.0;                                    // rows past n_occ: the identity
-            if (i < no) {
-#pragma unroll
-                for (int k = 0; k < i; ++k) s -= Lm[i][k] * x[k];      // uniform LDS addresses: broadcast reads; x[k] = 0 above the diagonal
-                x[i] = lane <= i ? s / (Lm[i][i] + (plus ? 1.0 : 0.0)) : 0.0;   // (1 + L) has the same strictly lower part
-            }
-            __builtin_amdgcn_sched_barrier(0);                               // row by row: hoisting every row's loads costs registers
+        const int lane = t & 63, col = lane < MAXO ? lane : MAXO - 1;
+        const double plus = t >= 64 ? 1.0 : 0.0;                // (1 + L) has the same strictly lower part
+        double (*Out)[MAXO + 1] = t >= 64 ? L1 : Li;
+        for (int i = 0; i < no; ++i) {
+            double s = col == i ? 1.0 : 0.0;
+            for (int k = 0; k < i; ++k) s -= Lm[i][k] * Out[k][col];   // Out[k][col] = 0 above the diagonal
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < MAXO) Out[i][col] = col <= i ? s / (Lm[i][i] + plus) : 0.0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        double (*Out)[MAXO + 1] = plus ? L1 : Li;
-#pragma unroll
-        for (int i = 0; i < MAXO; ++i)
-            if (lane < MAXO) Out[i][lane] = x[i];
+        if (lane < MAXO)
+            for (int i = no; i < MAXO; ++i) Out[i][col] = col == i ? 1.0 / (1.0 + plus) : 0.0;
     }
     __syncthreads();
 }
