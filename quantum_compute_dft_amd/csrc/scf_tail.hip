@@ -451,8 +451,15 @@ __device__ __forceinline__ void chol_and_inverses(int no, const double *Pm, doub
     if (t < 64) {
         const int lane = t, row = lane < MAXO ? lane : MAXO - 1;
         for (int j = 0; j < no; ++j) {
-            double s = Lm[row][j];
-            for (int k = 0; k < j; ++k) s -= Lm[row][k] * Lm[j][k];
+            double s = Lm[row][j], s2 = 0.0;
+            int k = 0;
+            for (; k + 4 <= j; k += 4) {   // four products' loads in flight, two chains
+                const double a0 = Lm[row][k], a1 = Lm[row][k + 1], a2 = Lm[row][k + 2], a3 = Lm[row][k + 3];
+                const double b0 = Lm[j][k], b1 = Lm[j][k + 1], b2 = Lm[j][k + 2], b3 = Lm[j][k + 3];
+                s = fma(-a0, b0, s); s2 = fma(-a1, b1, s2); s = fma(-a2, b2, s); s2 = fma(-a3, b3, s2);
+            }
+            for (; k < j; ++k) s = fma(-Lm[row][k], Lm[j][k], s);
+            s += s2;
             const double djj = sqrt(bcast(s, j));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every lane has read column j's inputs
             if (lane == j) Lm[j][j] = djj;
@@ -467,8 +474,15 @@ __device__ __forceinline__ void chol_and_inverses(int no, const double *Pm, doub
         const double plus = t >= 64 ? 1.0 : 0.0;                // (1 + L) has the same strictly lower part
         double (*Out)[MAXO + 1] = t >= 64 ? L1 : Li;
         for (int i = 0; i < no; ++i) {
-            double s = col == i ? 1.0 : 0.0;
-            for (int k = 0; k < i; ++k) s -= Lm[i][k] * Out[k][col];   // Out[k][col] = 0 above the diagonal
+            double s = col == i ? 1.0 : 0.0, s2 = 0.0;                  // Out[k][col] = 0 above the diagonal
+            int k = 0;
+            for (; k + 4 <= i; k += 4) {
+                const double a0 = Lm[i][k], a1 = Lm[i][k + 1], a2 = Lm[i][k + 2], a3 = Lm[i][k + 3];
+                const double b0 = Out[k][col], b1 = Out[k + 1][col], b2 = Out[k + 2][col], b3 = Out[k + 3][col];
+                s = fma(-a0, b0, s); s2 = fma(-a1, b1, s2); s = fma(-a2, b2, s); s2 = fma(-a3, b3, s2);
+            }
+            for (; k < i; ++k) s = fma(-Lm[i][k], Out[k][col], s);
+            s += s2;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane < MAXO) Out[i][col] = col <= i ? s / (Lm[i][i] + plus) : 0.0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

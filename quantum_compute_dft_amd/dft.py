@@ -115,8 +115,8 @@ def main(argv=None):
             st = eig_stats
             print(f"Eigensolver: {st['rotated']} cycles by occupied-subspace rotation ({st['inner_steps']} fixed-point steps), {st['exact']} by full diagonalisation")
         eig_dev = "occupied-subspace rotation, hipSOLVER eigh as fallback," if backend.occ_solver is not None else "hipSOLVER eigh"
-        print("Host part of the cycle: " + ("device-resident: Fock build, DIIS, occupied-subspace rotation, density and energy traces as six launches of "
-                                            "libdft.so (DFT_ScfTailStep); full diagonalisations by host LAPACK" if getattr(backend, "tail", None) is not None else
+        print("Host part of the cycle: " + ("device-resident: Fock build, DIIS, occupied-subspace rotation, density and energy traces as kernels of "
+                                            "libdft.so (DFT_ScfTailStep); full diagonalisations by " + ("hipSOLVER" if inp.shells.nao >= 400 else "host LAPACK") if getattr(backend, "tail", None) is not None else
                                             f"device-resident (Fock build, DIIS, {eig_dev} in HBM)" if backend.device_resident
                                             else "host LAPACK eigh; [dm|cocc] up and [J|K|Vxc] down in one pinned transfer each"))
         print("-" * 80)
