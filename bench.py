@@ -795,6 +795,8 @@ def main():
     line_lock = threading.Lock()       # members are added under it; the dump takes a copy under it
 
     def put(key, value):
+        if os.environ.get("QCDFT_BENCH_TRACE"):
+            print(f"[bench rank {rank}] leg done: {key}", file=sys.stderr, flush=True)
         if line is not None:
             with line_lock:
                 line[key] = value
@@ -873,6 +875,10 @@ def main():
             put("cpu_baseline", cpu_baseline(xc, dm, ao, gr, w, args.cpu_seconds))
     except Exception as e:   # noqa: BLE001 -- whatever a leg raises, the measured headline is still printed
         note = f"an extra leg failed ({type(e).__name__}: {e}); members present are complete"
+        import traceback
+        print(f"[bench rank {rank}] {note}", file=sys.stderr, flush=True)   # every rank says what it saw (only rank 0 owns the line)
+        traceback.print_exc(file=sys.stderr)
+        sys.stderr.flush()
     dog.cancel()
     emit(note)
     if note is not None:

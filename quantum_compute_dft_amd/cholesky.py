@@ -119,9 +119,7 @@ def _cholesky_eri_device(shells, tol, span, max_vectors, screen, verbose, device
                 Bt = torch.as_tensor(np.asarray(B), device=dev)
                 # V = G^-1 res[B]: the small triangular inverse on the host (r <= a few hundred), one GEMM on the device
                 # (rocBLAS's trsm wants a workspace it could not get for r x nao^2 right-hand sides above r ~ 100)
-                from scipy.linalg import solve_triangular
-                Ginv = solve_triangular(G, np.eye(r), lower=True)
-                V = torch.as_tensor(Ginv, device=dev) @ res[Bt]
+                V = torch.as_tensor(_lower_inverse(G), device=dev) @ res[Bt]
                 L[k:k + r] = V
                 k += r
                 diag -= (V * V).sum(0)
@@ -135,6 +133,17 @@ def _cholesky_eri_device(shells, tol, span, max_vectors, screen, verbose, device
         eri.close()
         if dcols is not None:
             dcols.close()
+
+
+def _lower_inverse(G):
+    """Inverse of a lower-triangular matrix by forward substitution, row by row (plain numpy: scipy's solve_triangular
+    crashed in its BLAS under OMP_NUM_THREADS=1, the setting torch.distributed.run gives every rank)."""
+    r = G.shape[0]
+    X = np.zeros((r, r))
+    for i in range(r):
+        X[i, :i] = -(G[i, :i] @ X[:i, :i]) / G[i, i]
+        X[i, i] = 1.0 / G[i, i]
+    return X
 
 
 def _block_pivots(A, floor, room):

@@ -197,3 +197,14 @@ def test_schwarz_bounds_and_block_pivots_of_the_device_cholesky():
     assert B == piv and len(B) == 5 and np.allclose(G, np.tril(G))
     assert np.abs(np.linalg.solve(G, R[B]) - np.array(vs)).max() < 1e-12
     assert _block_pivots(A, 1e-10, 2)[0] == piv[:2]                      # room for two more vectors only
+
+
+def test_lower_triangular_inverse_of_the_block_factor():
+    """cholesky._lower_inverse (the vectors of a step are G^-1 res[B]): exact inverse, lower-triangular, for the sizes a
+    joint block of eight shell pairs reaches."""
+    from quantum_compute_dft_amd.cholesky import _lower_inverse
+    rng = np.random.default_rng(11)
+    for r in (1, 2, 9, 49, 200):
+        G = np.tril(rng.standard_normal((r, r))) + (2.0 + np.sqrt(r)) * np.eye(r)
+        X = _lower_inverse(G)
+        assert np.abs(X @ G - np.eye(r)).max() <= 1e-12 and np.abs(np.triu(X, 1)).max() == 0.0
