@@ -76,3 +76,26 @@ def test_cholesky_with_device_columns_matches_host_columns(dev):
         approx = torch.einsum("pij,pkl->ijkl", L, L).cpu().numpy()
         assert np.abs(approx - eri).max() <= 1e-9
         assert float((L - L.transpose(1, 2)).abs().max()) == 0.0 or float((L - L.transpose(1, 2)).abs().max()) < 1e-14
+
+
+def test_many_pairs_in_one_call_equal_the_single_calls(dev):
+    """DFT_EriColumnsMany (the Cholesky factorisation's batched steps): blocks of several ket shell pairs written back to back by
+    kernels that run side by side, bit-identical to one DFT_EriColumns call per pair; the whole target range is cleared."""
+    syms, xyz = ["C", "H", "O"], np.array([[0.10, -0.20, 0.05], [1.25, 0.90, 1.60], [-1.9, 0.7, -0.4]])
+    sh = basis.build_shells(syms, xyz, "def2-svp")
+    host = integrals.EriColumns(sh)
+    devc = integrals.DeviceEriColumns(sh, integrals.schwarz_bounds(sh, host.diag()))
+    host.close()
+    n, ns = sh.nao, sh.nshell
+    pairs = [(ns - 1, 0), (2, 2), (1, 3), (ns - 2, ns - 3), (0, 0), (4, 1)]
+    nqs = [(2 * int(sh.l[C]) + 1) * (2 * int(sh.l[D]) + 1) for C, D in pairs]
+    buf = torch.full((sum(nqs) * n * n,), -3.0, dtype=torch.float64, device=dev)
+    many = devc.cols_many(pairs, 1e-14, buf).clone()
+    assert many.shape == (sum(nqs), n, n)
+    one = torch.empty((max(nqs) * n * n,), dtype=torch.float64, device=dev)
+    o = 0
+    for (C, D), nq in zip(pairs, nqs):
+        ref = devc.cols(C, D, 1e-14, one)
+        assert torch.equal(many[o:o + nq], ref), (C, D)
+        o += nq
+    devc.close()
