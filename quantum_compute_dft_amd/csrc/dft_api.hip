@@ -78,6 +78,7 @@ struct XCSolver {
     int ws_waves = 0;  // wave-specialised kernels (nao <= 128): 0 auto, 8 = 4+4 waves per workgroup, 16 = 8+8
     int occ = 0;       // DFT_ComputeXCOcc: 0 auto (occupied-orbital density step where it does fewer MFMAs), 1 always, 2 never
     int used_occ = 0;  // what the last sweep did (DFT_GetTimings names say so too)
+    int eri_sym = 0;   // 1: the caller vouches that the dense ERI is symmetric as an (N2, N2) matrix: DFT_ComputeCoulomb streams its upper triangle only
     // A synchronous call seen before with the same pointers and sizes is replayed as one recorded HIP graph (one submission
     // instead of five launches): -1 auto = where the call is launch-bound (planes of at most GRAPH_AUTO_ELEMS doubles: H2O/def2-SVP
     // 30.4 -> 26.3 us per LDA call, 34.7 -> 32.9 GGA; Benzene/STO-3G 84.5 -> 86.0 and Benzene/def2-SVP 228.4 -> 230.6, so not there),
@@ -451,6 +452,17 @@ void jk(XCSolver *s, int nao, const double *eri, const double *dm, double *J, do
     const size_t N2 = (size_t)n * n;
     const int KB = std::max(1, std::min(n, JK_COLS / n));
     const int ncb = (n + KB - 1) / KB;
+    if (J && !K && s->eri_sym && i0 == 0 && ni == n) {   // upper triangle only (k_j_sym)
+        const int nslab = n + ncb;
+        if (!reserve(s, s->jpart, sizeof(double) * nslab * N2, "hipMalloc(Jpart)")) return;
+        double *jp = (double *)s->jpart.p;
+        const bool vec = (n % 2 == 0) && (((uintptr_t)eri & 15) == 0);
+        if (vec) hipLaunchKernelGGL((k_j_sym<true>), dim3(ncb, n), dim3(256), 0, s->stream, n, KB, eri, dm, jp);
+        else     hipLaunchKernelGGL((k_j_sym<false>), dim3(ncb, n), dim3(256), 0, s->stream, n, KB, eri, dm, jp);
+        hipLaunchKernelGGL(k_sum_slabs8, dim3((unsigned)((N2 + 31) / 32)), dim3(256), 0, s->stream, N2, nslab, N2, jp, J);
+        hip_ok(s, hipGetLastError(), "J launch");
+        return;
+    }
     // enough workgroups to fill the chip: split the j range when ni*ncb is small
     int jsplit = 1;
     while ((long)ni * ncb * jsplit < 4L * s->num_cu && jsplit * 2 <= n) jsplit *= 2;
@@ -1080,6 +1092,7 @@ int DFT_SetOption(XCSolver *s, const char *key, double value)
         DeviceGuard dg(s);
         drop_graphs(s); // recorded sweeps were launched under the old options
     }
+    if (!strcmp(key, "eri_symmetric")) { s->eri_sym = value != 0.0; return 0; }
     if (!strcmp(key, "graph")) { s->graph = value > 0.0 ? 1 : value < 0.0 ? -1 : 0; return 0; }
     if (!strcmp(key, "quirks")) { s->quirks = value != 0.0; return 0; }
     if (!strcmp(key, "path")) { s->path = (int)value; return 0; }

@@ -17,6 +17,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "device_util.hpp"
+
 namespace qcdft {
 
 constexpr int JK_COLS = 1024; // columns per workgroup (4 per thread)
@@ -92,6 +94,77 @@ __global__ __launch_bounds__(256) void k_jk_stream(int n, int KB, int jsplit, in
             Kpart[((size_t)js * ni + il) * n + klo + tid] = s;
         }
     }
+}
+
+// J alone from an ERI that is SYMMETRIC as an (N2, N2) matrix ((ij|kl) = (kl|ij), which every real ERI is): only its upper
+// triangle is streamed -- half the bytes of the pass above, which is all there is to a Coulomb build.  Element e = eri[r][c],
+// c >= r, contributes e dm[r] to J[c] (column partials in registers, as above) and, for c > r, e dm[c] to J[r] (a row sum: a
+// wave reduction per row, added up over the workgroup's four waves at the end).  Workgroup (b, i): rows (i, 0..n-1), columns of
+// k-segments [b KB, b KB + KB); blocks left of the diagonal only write zeros.  Slabs: i = 0..n-1 hold the column partials,
+// n + b the row partials of column block b; k_sum_slabs8 adds them in a fixed order.  Opt-in (DFT_SetOption "eri_symmetric"):
+// DFT_ComputeCoulomb's contract is eri^T . vec(dm) for ANY matrix (dft_solver.cu:550-555), which this kernel does not honour.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_j_sym(int n, int KB, const double *__restrict__ eri, const double *__restrict__ dm,
+                                               double *__restrict__ Jpart)
+{
+    __shared__ double rp[4][JK_COLS];
+    const size_t N2 = (size_t)n * n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, i = blockIdx.y;
+    const int klo = b * KB, khi = min(n, klo + KB);
+    const int ncol = (khi - klo) * n;
+    const size_t cbase = (size_t)klo * n, rmin = (size_t)i * n;
+    double *colpart = Jpart + (size_t)i * N2 + cbase;
+    double *rowpart = Jpart + (size_t)(n + b) * N2 + rmin;
+    int col[4];
+    size_t g[4];
+    double dcol[4], ja[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        col[q] = VEC ? 2 * tid + (q & 1) + 512 * (q >> 1) : tid + 256 * q;
+        g[q] = cbase + col[q];
+        dcol[q] = col[q] < ncol ? dm[g[q]] : 0.0;
+    }
+    if (cbase + ncol <= rmin) {   // wholly below the diagonal
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (col[q] < ncol) colpart[col[q]] = 0.0;
+        for (int j = tid; j < n; j += 256) rowpart[j] = 0.0;
+        return;
+    }
+    for (int j = 0; j < n; ++j) {
+        const size_t r = rmin + j;
+        const double *row = eri + r * N2 + cbase;
+        const double dr = dm[r];
+        double e[4] = {0, 0, 0, 0};
+        if (VEC) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (col[2 * h] < ncol && g[2 * h + 1] >= r) {   // the pair reaches the diagonal or lies right of it
+                    const double2 v = *reinterpret_cast<const double2 *>(row + col[2 * h]);
+                    e[2 * h] = v.x;
+                    e[2 * h + 1] = v.y;
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (col[q] < ncol && g[q] >= r) e[q] = row[col[q]];
+        }
+        double racc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (g[q] >= r) ja[q] = fma(e[q], dr, ja[q]);
+            if (g[q] > r) racc = fma(e[q], dcol[q], racc);
+        }
+        racc = row16_sum(racc);
+        const double tot = (__shfl(racc, 0, 64) + __shfl(racc, 16, 64)) + (__shfl(racc, 32, 64) + __shfl(racc, 48, 64));
+        if (lane == 0) rp[wave][j] = tot;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (col[q] < ncol) colpart[col[q]] = ja[q];
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) rowpart[j] = (rp[0][j] + rp[1][j]) + (rp[2][j] + rp[3][j]);
 }
 
 // out[e] = sum_s part[s*stride + e] in a fixed order: 32 elements x 8 slab groups per block.

@@ -366,6 +366,10 @@ class HipBackend:
             self.eri_rows = (rlo, rhi)
             if rhi > rlo:
                 self.d_eri = torch.as_tensor(np.ascontiguousarray(inp.eri.reshape(nao * nao, nao * nao)[rlo:rhi]), dtype=f64, device=self.dev)
+            # (ij|kl) = (kl|ij): when the matrix in HBM really is symmetric (checked here, once) and only J is wanted, the Coulomb
+            # pass streams its upper triangle alone -- half the bytes of dft_solver.cu:550-555's GEMV, which is all a J build costs
+            if world == 1 and self.functional != "B3LYP" and self.d_eri is not None and bool(torch.equal(self.d_eri, self.d_eri.T)):
+                self.solver.set_option("eri_symmetric", 1)
         else:  # factorised J/K (DFT_ComputeJKFactorized): Cholesky vectors stay resident instead of the ERI
             if getattr(inp, "chol_range", None) is not None:      # inputs.build(world > 1) handed over this rank's slice only
                 self.d_chol = torch.as_tensor(inp.chol, dtype=f64, device=self.dev)

@@ -666,3 +666,38 @@ def test_more_than_2_31_ao_elements(dev):
     assert np.abs(d_v.cpu().numpy() - R * v_ref).max() <= 1e-9 * R * np.abs(v_ref).max()
     del d_ao, d_w
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n", [5, 24, 33, 57, 114])
+def test_coulomb_from_the_upper_triangle_of_a_symmetric_eri(n):
+    """Option "eri_symmetric" (k_j_sym): J from the upper triangle of an ERI that is symmetric as an (n^2, n^2) matrix equals the
+    full pass (the reference's GEMV, dft_solver.cu:550-555) to rounding; without the option a NON-symmetric matrix still gives
+    eri^T . vec(dm), and with it the lower triangle is never read."""
+    import torch
+    import quantum_compute_dft_amd as q
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(100 + n)
+    N2 = n * n
+    A = torch.randn((N2, N2), dtype=torch.float64, device=dev, generator=g)
+    E = (A + A.T).contiguous()
+    d = torch.randn((n, n), dtype=torch.float64, device=dev, generator=g)
+    d = (d + d.T).contiguous()
+    ref = (E.T @ d.reshape(-1)).reshape(n, n)
+    s = q.DFTSolverWrapper(q.library_path(), "GGA")
+    J0 = torch.zeros((n, n), dtype=torch.float64, device=dev); J1 = torch.zeros_like(J0); J2 = torch.zeros_like(J0)
+    s.compute_coulomb(n, E, d, J0)
+    s.set_option("eri_symmetric", 1)
+    s.compute_coulomb(n, E, d, J1)
+    scale = float(ref.abs().max())
+    assert float((J0 - ref).abs().max()) <= 1e-12 * scale and float((J1 - ref).abs().max()) <= 1e-12 * scale
+    J1b = torch.zeros_like(J0)
+    s.compute_coulomb(n, E, d, J1b)
+    assert torch.equal(J1, J1b)                                     # deterministic
+    L = torch.triu(E) + 1e3 * torch.tril(torch.ones_like(E), -1)    # garbage below the diagonal: never read
+    s.compute_coulomb(n, L.contiguous(), d, J2)
+    assert torch.equal(J1, J2)
+    s.set_option("eri_symmetric", 0)
+    Ens = A.contiguous()                                            # not symmetric: the reference's contract
+    s.compute_coulomb(n, Ens, d, J2)
+    refn = (Ens.T @ d.reshape(-1)).reshape(n, n)
+    assert float((J2 - refn).abs().max()) <= 1e-12 * float(refn.abs().max())
