@@ -132,33 +132,50 @@ __global__ __launch_bounds__(256) void k_j_sym(int n, int KB, const double *__re
         for (int j = tid; j < n; j += 256) rowpart[j] = 0.0;
         return;
     }
-    for (int j = 0; j < n; ++j) {
-        const size_t r = rmin + j;
-        const double *row = eri + r * N2 + cbase;
-        const double dr = dm[r];
-        double e[4] = {0, 0, 0, 0};
-        if (VEC) {
+    // four rows per turn: their loads are in flight together and their four row sums go through the reduction side by side
+    for (int j0 = 0; j0 < n; j0 += 4) {
+        double e[4][4], dr[4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-                if (col[2 * h] < ncol && g[2 * h + 1] >= r) {   // the pair reaches the diagonal or lies right of it
-                    const double2 v = *reinterpret_cast<const double2 *>(row + col[2 * h]);
-                    e[2 * h] = v.x;
-                    e[2 * h + 1] = v.y;
-                }
-        } else {
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            const bool live = j < n;
+            const size_t r = rmin + (live ? j : 0);
+            const double *row = eri + r * N2 + cbase;
+            dr[u] = live ? dm[r] : 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (col[q] < ncol && g[q] >= r) e[q] = row[col[q]];
+            for (int q = 0; q < 4; ++q) e[u][q] = 0.0;
+            if (VEC) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if (live && col[2 * h] < ncol && g[2 * h + 1] >= r) {   // the pair reaches the diagonal or lies right of it
+                        const double2 v = *reinterpret_cast<const double2 *>(row + col[2 * h]);
+                        e[u][2 * h] = v.x;
+                        e[u][2 * h + 1] = v.y;
+                    }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (live && col[q] < ncol && g[q] >= r) e[u][q] = row[col[q]];
+            }
         }
-        double racc = 0.0;
+        double racc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (g[q] >= r) ja[q] = fma(e[q], dr, ja[q]);
-            if (g[q] > r) racc = fma(e[q], dcol[q], racc);
+        for (int u = 0; u < 4; ++u) {
+            const size_t r = rmin + j0 + u;
+            racc[u] = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (g[q] >= r) ja[q] = fma(e[u][q], dr[u], ja[q]);      // (rows past n carry zeros)
+                if (g[q] > r) racc[u] = fma(e[u][q], dcol[q], racc[u]);
+            }
         }
-        racc = row16_sum(racc);
-        const double tot = (__shfl(racc, 0, 64) + __shfl(racc, 16, 64)) + (__shfl(racc, 32, 64) + __shfl(racc, 48, 64));
-        if (lane == 0) rp[wave][j] = tot;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) racc[u] = row16_sum(racc[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double tot = (__shfl(racc[u], 0, 64) + __shfl(racc[u], 16, 64)) + (__shfl(racc[u], 32, 64) + __shfl(racc[u], 48, 64));
+            if (lane == 0 && j0 + u < n) rp[wave][j0 + u] = tot;
+        }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
