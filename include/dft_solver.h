@@ -247,7 +247,7 @@ void DFT_EriColumnsClose(void *handle);
  *   Wait    blocks (polling host-mapped memory) until the last Step / Finish has completed; out[0..6] = tr(dm' Hcore),
  *           tr(dm' J)/2, -c_hf tr(dm' K)/4, |dm' - dm|_F, status, fixed-point steps, Jacobi sweeps, Exc (see d_exc).  status 0: done;
  *           1: diagonalise d_fock_out yourself, then Finish; 2: the DIIS system was singular (DFT_ScfTailGram copies the
- *           8 x 8 Gram matrix of the ring to the host: solve it there and repeat the Step with `coef`).
+ *           8 x 8 Gram matrix of the ring to the host: solve it there and repeat the Step with `coef`); 3: see DFT_ScfTailMore.
  * Everything is asynchronous on the handle's stream except Wait and Gram.  0 on success, -1 on error. */
 void *DFT_ScfTailOpen(int nao, int nocc, unsigned long long d_hcore, unsigned long long d_overlap, unsigned long long d_basis,
                       unsigned long long d_fock_out, unsigned long long d_mo_energy);
@@ -257,6 +257,12 @@ int DFT_ScfTailStep(void *handle, int rotate, double c_hf, double tol, double ca
                     unsigned long long d_vraw, unsigned long long d_dm, unsigned long long d_cocc, unsigned long long d_exc);
 int DFT_ScfTailFinish(void *handle, double c_hf, unsigned long long d_J, unsigned long long d_K, unsigned long long d_dm,
                       unsigned long long d_cocc);
+/* Above 128 functions / 32 occupied orbitals the rotation's fixed-point steps are launches of their own, queued in advance
+ * (SetStepsHint: how many per Step, 1..60, default 6); status 3 from Wait = they were not enough: More queues `nsteps` more and
+ * the rest of the step again (same matrices as the Step it continues), then Wait again. */
+int DFT_ScfTailMore(void *handle, int nsteps, unsigned long long d_J, unsigned long long d_K, unsigned long long d_dm,
+                    unsigned long long d_cocc, unsigned long long d_exc);
+int DFT_ScfTailSetStepsHint(void *handle, int nsteps);
 int DFT_ScfTailWait(void *handle, double *out8);
 int DFT_ScfTailGram(void *handle, double *host_out64);
 int DFT_ScfTailStamps(void *handle, long long *host_out16);   /* diagnostics: 100 MHz stamps of the rotation kernel's phases */

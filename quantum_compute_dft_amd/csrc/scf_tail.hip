@@ -51,6 +51,8 @@ struct TailArgs {
     double c_hf, tol, canon_tol;
 };
 
+struct RbState;
+
 struct RotLds {   // offsets (doubles) into the rotation kernel's dynamic LDS; -1 = the matrix stays in memory
     int km, bm, qm, rm, smalls;
 };
@@ -62,6 +64,9 @@ struct TailDev {
     double *blob = nullptr;                                   // everything below
     double *Fb, *Eb, *Gb, *FC, *SC, *gpart, *FU, *A, *Unew, *Km, *Rm, *Qm, *Bm, *epart, *rden, *smalls, *Kfix, *KXg, *Kt, *Kt2, *K2;
     bool big = false;           // k_tail_rot_big: operands in memory
+    RbState *state = nullptr;   // the memory-resident fixed point's state (device)
+    int steps_hint = 6;         // fixed-point steps queued per DFT_ScfTailStep on that path
+    TailArgs last{};            // of the last step: DFT_ScfTailMore continues it
     int *status = nullptr;     // [0] status, [1] inner steps, [2] Jacobi sweeps, [3] ticket
     double *h_out = nullptr, *h_out_dev = nullptr;            // host-mapped: 8 doubles + sequence word
     unsigned long seq = 0;
@@ -764,14 +769,141 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
 #undef QCDFT_STAMP
 }
 
+// ---- the fixed point of the memory-resident rotation as launches of its own ------------------------------------------------
+// At Anthracene's sizes a fixed-point step inside ONE workgroup costs 83 us (246 functions) to 250 us (494): its 90-odd
+// tiles queue up on eight waves.  As three small launches per step they spread over the chip (~20 us per step); the
+// iteration's state (converged / failed, step count, which of the two K buffers is current, the last residual) lives in
+// memory, every kernel of a step returns at once when the iteration is over, and the host queues a few more steps than the
+// last cycle needed (status 3 asks for more).
+struct RbState {
+    int done, ok, steps, cur;
+    double prev;
+    unsigned long long rmax_bits;
+};
+
+// one 16 x 16 tile of A B on four waves (the contraction dealt to them), summed into wave 0's registers; see k_tail_gemm
+__device__ __forceinline__ void tile_splitk(int i0, int j0, int M, int N, int Kd, const double *a, int ars, int acs, const double *b, int brs,
+                                            int bcs, double (*part)[4][64], double (&out)[4])
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, kq = lane >> 4;
+    const int ia = i0 + li, jb = j0 + li;
+    const bool aok = ia < M, bok = jb < N;
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < Kd; k0 += 128) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = k0 + 4 * (4 * s + wave) + kq;
+            av[s] = aok && k < Kd ? a[(size_t)ia * ars + (size_t)k * acs] : 0.0;
+            bv[s] = bok && k < Kd ? b[(size_t)k * brs + (size_t)jb * bcs] : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; s += 2) {
+            acc0 = mfma_f64(av[s], bv[s], acc0);
+            acc1 = mfma_f64(av[s + 1], bv[s + 1], acc1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc0[r] + acc1[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = (part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane]);
+}
+
+// Qt = Aov + K^T Avv (tiles [0, ntq)) and Bt = Aoo + K^T Avo (the rest), K = the current buffer
+__global__ __launch_bounds__(256) void k_rb_qb(const RbState *__restrict__ st, int n, int no, const double *__restrict__ A,
+                                               const double *K0, const double *K1, double *__restrict__ Qt, double *__restrict__ Bt)
+{
+    __shared__ double part[4][4][64];
+    if (st->done) return;
+    const int nv = n - no, nto = (no + 15) >> 4, ntv = (nv + 15) >> 4, ntq = nto * ntv;
+    const double *K = st->cur ? K1 : K0;
+    const double *Aoo = A, *Aov = A + no, *Avo = A + (size_t)no * n, *Avv = A + (size_t)no * n + no;
+    const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+    double v[4];
+    if ((int)blockIdx.x < ntq) {
+        const int i0 = ((int)blockIdx.x / ntv) << 4, j0 = ((int)blockIdx.x % ntv) << 4;
+        tile_splitk(i0, j0, no, nv, nv, K, 1, no, Avv, n, 1, part, v);
+        if (threadIdx.x < 64)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + kq + 4 * r, col = j0 + li;
+                if (row < no && col < nv) Qt[(size_t)row * nv + col] = v[r] + Aov[(size_t)row * n + col];
+            }
+    } else {
+        const int tb = (int)blockIdx.x - ntq, i0 = (tb / nto) << 4, j0 = (tb % nto) << 4;
+        tile_splitk(i0, j0, no, no, nv, K, 1, no, Avo, n, 1, part, v);
+        if (threadIdx.x < 64)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + kq + 4 * r, col = j0 + li;
+                if (row < no && col < no) Bt[(size_t)row * no + col] = v[r] + Aoo[(size_t)row * n + col];
+            }
+    }
+}
+
+// Rt = Qt - Bt Kt; the residual's maximum into the state; the tentative update K - R / (a_v - a_o) into the OTHER K buffers
+__global__ __launch_bounds__(256) void k_rb_r(RbState *st, int n, int no, const double *__restrict__ Qt, const double *__restrict__ Bt,
+                                              const double *__restrict__ rdt, double *K0, double *K1, double *Kt0, double *Kt1)
+{
+    __shared__ double part[4][4][64];
+    if (st->done) return;
+    const int nv = n - no, ntv = (nv + 15) >> 4;
+    const int cur = st->cur;
+    const double *Kt = cur ? Kt1 : Kt0;
+    double *Kn = cur ? K0 : K1, *Ktn = cur ? Kt0 : Kt1;
+    const int i0 = ((int)blockIdx.x / ntv) << 4, j0 = ((int)blockIdx.x % ntv) << 4;
+    const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+    double v[4];
+    tile_splitk(i0, j0, no, nv, no, Bt, no, 1, Kt, nv, 1, part, v);
+    if (threadIdx.x < 64) {
+        double rm = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = i0 + kq + 4 * r, col = j0 + li;
+            if (row < no && col < nv) {
+                const size_t e = (size_t)row * nv + col;
+                const double res = Qt[e] - v[r];
+                const double x = fabs(res);
+                rm = (x == x) ? fmax(rm, x) : INFINITY;
+                const double kn = Kt[e] - res * rdt[e];
+                Ktn[e] = kn;
+                Kn[(size_t)col * no + row] = kn;
+            }
+        }
+        rm = wave_max(rm);
+        if (lane == 0) atomicMax(&st->rmax_bits, (unsigned long long)__double_as_longlong(rm));   // r >= 0: the bit patterns order like the values
+    }
+}
+
+__global__ void k_rb_decide(RbState *st, double tol, int max_inner)
+{
+    if (st->done) return;
+    const double r = __longlong_as_double((long long)st->rmax_bits);
+    st->steps += 1;
+    if (r < tol) { st->ok = 1; st->done = 1; return; }                 // the current K stands (Qt, Bt belong to it)
+    if (!(r < 4.0 * st->prev) || st->steps >= max_inner) { st->done = 1; return; }   // diverging, NaN, or out of steps
+    st->prev = fmin(st->prev, r);
+    st->cur ^= 1;
+    st->rmax_bits = 0ULL;
+}
+
+__global__ void k_tail_clear_more(int *status)
+{
+    if (status[0] == 3) status[0] = 0;
+}
+
 // The same rotation for sizes whose matrices do not fit the LDS (nao <= 512, nocc <= 64; Anthracene: 246 / 494 functions, 47
 // occupied): one workgroup again -- a barrier across workgroups costs 4 us plus 0.3 us per workgroup on this chip
 // (tools/gridsync_probe.hip, agent-scope fences either side), more than the phases it would separate -- with every operand in
 // memory (L2-resident: A is 0.5-2 MB) behind generic pointers, the n_occ x n_occ triangular matrices alone in LDS.
 __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot_big(TailArgs a, const double *__restrict__ A, double *Km, double *K2, double *Kt,
                                                            double *Kt2, double *Qt, double *Rt, double *Bt, double *rdt, double *smalls,
-                                                           double *W, double *eig, int *status, long long *stamps, double *Kfix, double *KXg)
+                                                           double *W, double *eig, int *status, long long *stamps, double *Kfix, double *KXg,
+                                                           int mode, RbState *st)
 {
+    // mode 0: everything here; 1: the start only (K0, its test, the iteration's state) -- the steps run as launches of
+    // their own (k_rb_qb / k_rb_r / k_rb_decide); 2: the completion only, from the state those left
 #define QCDFT_STAMP(k) do { if (threadIdx.x == 0) stamps[k] = (long long)wall_clock64(); } while (0)
     extern __shared__ double dyn[];   // L, L^-1, (1 + L)^-1; the Jacobi columns reuse the last two
     __shared__ double dd[TL_BIGN], red[TL_ROT_T / 64];
@@ -782,6 +914,9 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot_big(TailArgs a, const dou
     const double *Aoo = A, *Aov = A + no, *Avo = A + (size_t)no * n, *Avv = A + (size_t)no * n + no;
     for (int i = t; i < n; i += TL_ROT_T) dd[i] = A[(size_t)i * n + i];
     __syncthreads();
+    bool ok = false;
+    int steps = 0;
+    if (mode != 2) {
     // K lives twice, as K[v][o] and as its transpose Kt[o][v]: with both, every large operand below is read along its rows
     // (16 lanes x 8 B from one 128-byte line; the strided alternative touches 16 lines per load and is bound by that, 4x slower)
     double kmax = 0.0;
@@ -797,13 +932,15 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot_big(TailArgs a, const dou
     }
     kmax = block_max(kmax, red);
     if (!(kmax <= 0.5)) {
-        if (t == 0) status[0] = 1;
+        if (t == 0) { status[0] = 1; if (mode == 1) { st->done = 1; st->ok = 0; st->steps = 0; } }
         return;
     }
     QCDFT_STAMP(1);
+    if (mode == 1) {
+        if (t == 0) { st->done = 0; st->ok = 0; st->steps = 0; st->cur = 0; st->prev = INFINITY; st->rmax_bits = 0ULL; }
+        return;
+    }
     double prev = INFINITY;
-    bool ok = false;
-    int steps = 0;
     for (int it = 0; it < a.max_inner; ++it) {
         // Qt = (Avo + Avv K)^T = Aov + K^T Avv,  Bt = (Aoo + Aov K)^T = Aoo + K^T Avo   (A symmetric)
         wg_gemm(no, nv, nv, Km, 1, no, Avv, n, 1, 1.0, 1.0, Aov, n, Qt, nv);
@@ -842,6 +979,15 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot_big(TailArgs a, const dou
         prev = fmin(prev, r);
         { double *tmp = Km; Km = K2; K2 = tmp; tmp = Kt; Kt = Kt2; Kt2 = tmp; }
         if (it == 0) QCDFT_STAMP(4);
+    }
+    } else {   // mode 2: what the step launches left
+        if (!st->done) {
+            if (t == 0) status[0] = 3;   // more steps, please
+            return;
+        }
+        ok = st->ok != 0;
+        steps = st->steps;
+        if (st->cur) { Km = K2; Kt = Kt2; }
     }
     QCDFT_STAMP(5);
     if (t == 0) status[1] = steps;
@@ -1051,6 +1197,17 @@ __global__ void k_tail_begin(int *status)
     status[0] = 0; status[1] = 0; status[2] = 0;
 }
 
+// `nsteps` fixed-point steps of the memory-resident rotation, three launches each (they return at once when the iteration is over)
+void launch_big_steps(TailDev *c, const TailArgs &a, int nsteps)
+{
+    const int n = c->n, no = c->no, nv = n - no, nto = (no + 15) / 16, ntv = (nv + 15) / 16;
+    for (int k = 0; k < nsteps; ++k) {
+        hipLaunchKernelGGL(k_rb_qb, dim3(nto * ntv + nto * nto), dim3(256), 0, c->stream, c->state, n, no, c->A, c->Km, c->K2, c->Qm, c->Bm);
+        hipLaunchKernelGGL(k_rb_r, dim3(nto * ntv), dim3(256), 0, c->stream, c->state, n, no, c->Qm, c->Bm, c->rden, c->Km, c->K2, c->Kt, c->Kt2);
+        hipLaunchKernelGGL(k_rb_decide, dim3(1), dim3(1), 0, c->stream, c->state, a.tol, a.max_inner);
+    }
+}
+
 void tail_error(TailDev *c, const char *what, hipError_t e)
 {
     snprintf(c->err, sizeof c->err, "%s: %s", what, hipGetErrorString(e));
@@ -1077,8 +1234,8 @@ void *DFT_ScfTailOpen(int nao, int nocc, unsigned long long d_hcore, unsigned lo
                             nv * no, nv * no, nv * no, no * no, 4 * n, bigk, c->big ? 10 * no * no : 0, bigk, bigk, bigk, bigk, bigk};
     size_t total = 0;
     for (size_t s : sizes) total += (s + 1) & ~(size_t)1;
-    if (hipMalloc((void **)&c->blob, total * sizeof(double) + 256) != hipSuccess ||
-        hipMemset(c->blob, 0, total * sizeof(double) + 256) != hipSuccess ||
+    if (hipMalloc((void **)&c->blob, total * sizeof(double) + 512) != hipSuccess ||
+        hipMemset(c->blob, 0, total * sizeof(double) + 512) != hipSuccess ||
         hipHostMalloc((void **)&c->h_out, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->h_out_dev, c->h_out, 0) != hipSuccess) {
         (void)hipGetLastError();
@@ -1095,6 +1252,7 @@ void *DFT_ScfTailOpen(int nao, int nocc, unsigned long long d_hcore, unsigned lo
         p += (sizes[i] + 1) & ~(size_t)1;
     }
     c->status = (int *)p;
+    c->state = (RbState *)(c->status + 40);   // [0..3] status words, [8..39] the rotation kernels' stamps, then the state
     memset(c->h_out, 0, 16 * sizeof(double));
     // k_tail_rot: A in LDS during the fixed point (the completion's small matrices reuse its space), then K, B, Q, R as 160 KB allow
     {
@@ -1166,6 +1324,7 @@ int DFT_ScfTailStep(void *h, int rotate, double c_hf, double tol, double canon_t
     }
     if (!has_slot) { snprintf(c->err, sizeof c->err, "DFT_ScfTailStep: the new slot is not in the history"); return -1; }
     a.c_hf = c_hf; a.tol = tol; a.canon_tol = canon_tol > 0.0 ? canon_tol : 1e-3;
+    c->last = a;
     const int n = c->n;
     const double *J = (const double *)d_J, *K = (const double *)d_K, *V = (const double *)d_vraw;
     double *dm = (double *)d_dm, *cocc = (double *)d_cocc;
@@ -1186,7 +1345,10 @@ int DFT_ScfTailStep(void *h, int rotate, double c_hf, double tol, double canon_t
             const int no = c->no, nv = n - no, ntv = (nv + 15) / 16, nto = (no + 15) / 16;
             double *W = c->FU;
             hipLaunchKernelGGL(k_tail_rot_big, dim3(1), dim3(TL_ROT_T), c->rot_lds, st, a, c->A, c->Km, c->K2, c->Kt, c->Kt2, c->Qm, c->Rm, c->Bm,
-                               c->rden, c->smalls, W, c->eig, c->status, stamps, c->Kfix, c->KXg);
+                               c->rden, c->smalls, W, c->eig, c->status, stamps, c->Kfix, c->KXg, 1, c->state);
+            launch_big_steps(c, a, c->steps_hint);
+            hipLaunchKernelGGL(k_tail_rot_big, dim3(1), dim3(TL_ROT_T), c->rot_lds, st, a, c->A, c->Km, c->K2, c->Kt, c->Kt2, c->Qm, c->Rm, c->Bm,
+                               c->rden, c->smalls, W, c->eig, c->status, stamps, c->Kfix, c->KXg, 2, c->state);
             hipLaunchKernelGGL(k_tail_gemm, dim3(nto * ntv), dim3(256), 0, st, no, nv, no, c->smalls + 9 * (size_t)no * no, no, 1, c->Kfix, 1, no,
                                W + no, n, -1.0, 0, c->status);                                         // -(1 + M X) K^T
             hipLaunchKernelGGL(k_tail_gemm, dim3(ntv * ntv), dim3(256), 0, st, nv, nv, no, c->KXg, no, 1, c->Kfix, 1, no,
@@ -1200,6 +1362,43 @@ int DFT_ScfTailStep(void *h, int rotate, double c_hf, double tol, double canon_t
                        c->status, (const double *)d_exc, c->h_out_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { tail_error(c, "SCF tail launch", e); return -1; }
+    return 0;
+}
+
+// After status 3 (the memory-resident rotation ran out of queued fixed-point steps): `nsteps` more, then the rest of the step.
+int DFT_ScfTailMore(void *h, int nsteps, unsigned long long d_J, unsigned long long d_K, unsigned long long d_dm, unsigned long long d_cocc,
+                    unsigned long long d_exc)
+{
+    TailDev *c = (TailDev *)h;
+    if (!c || !c->big || !d_J || !d_dm || !d_cocc || nsteps < 1) return -1;
+    c->err[0] = 0;
+    const TailArgs a = c->last;
+    const int n = c->n, no = c->no, nv = n - no, nt = (n + 15) / 16, ntv = (nv + 15) / 16, nto = (no + 15) / 16;
+    hipStream_t st = c->stream;
+    double *W = c->FU;
+    const unsigned long seq = ++c->seq;
+    hipLaunchKernelGGL(k_tail_clear_more, dim3(1), dim3(1), 0, st, c->status);
+    launch_big_steps(c, a, nsteps);
+    hipLaunchKernelGGL(k_tail_rot_big, dim3(1), dim3(TL_ROT_T), c->rot_lds, st, a, c->A, c->Km, c->K2, c->Kt, c->Kt2, c->Qm, c->Rm, c->Bm,
+                       c->rden, c->smalls, W, c->eig, c->status, (long long *)(c->status + 8), c->Kfix, c->KXg, 2, c->state);
+    hipLaunchKernelGGL(k_tail_gemm, dim3(nto * ntv), dim3(256), 0, st, no, nv, no, c->smalls + 9 * (size_t)no * no, no, 1, c->Kfix, 1, no,
+                       W + no, n, -1.0, 0, c->status);
+    hipLaunchKernelGGL(k_tail_gemm, dim3(ntv * ntv), dim3(256), 0, st, nv, nv, no, c->KXg, no, 1, c->Kfix, 1, no,
+                       W + (size_t)no * n + no, n, 1.0, 1, c->status);
+    hipLaunchKernelGGL(k_tail_gemm, dim3(nt * nt), dim3(256), 0, st, n, n, n, c->U, n, 1, c->FU, n, 1, c->Unew, n, 1.0, 0, c->status);
+    hipLaunchKernelGGL(k_tail_density, dim3(n), dim3(128), 0, st, a, 0, seq, c->H, (const double *)d_J, (const double *)d_K, c->U, c->Unew,
+                       (double *)d_dm, (double *)d_cocc, c->epart, c->status, (const double *)d_exc, c->h_out_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { tail_error(c, "SCF tail launch", e); return -1; }
+    return 0;
+}
+
+// Fixed-point steps queued per DFT_ScfTailStep on the memory-resident path (the caller knows how many the last cycle took)
+int DFT_ScfTailSetStepsHint(void *h, int nsteps)
+{
+    TailDev *c = (TailDev *)h;
+    if (!c) return -1;
+    c->steps_hint = nsteps < 1 ? 1 : nsteps > 60 ? 60 : nsteps;
     return 0;
 }
 

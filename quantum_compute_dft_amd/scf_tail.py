@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 
 MAX_NAO, MAX_NOCC, SPACE = 512, 64, 8      # up to 128 x 32 the rotation's matrices live in LDS (k_tail_rot), above in memory (k_tail_rot_big)
-STATUS_DONE, STATUS_DIAGONALISE, STATUS_SINGULAR = 0, 1, 2
+STATUS_DONE, STATUS_DIAGONALISE, STATUS_SINGULAR, STATUS_MORE = 0, 1, 2, 3
 
 
 def supported(nao, nocc):
@@ -27,6 +27,8 @@ class ScfTail:
         lib.DFT_ScfTailStep.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, ip, dp, u64, u64, u64, u64, u64, u64]
         lib.DFT_ScfTailFinish.argtypes = [ctypes.c_void_p, ctypes.c_double, u64, u64, u64, u64]
+        lib.DFT_ScfTailMore.argtypes = [ctypes.c_void_p, ctypes.c_int, u64, u64, u64, u64, u64]
+        lib.DFT_ScfTailSetStepsHint.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.DFT_ScfTailWait.argtypes = [ctypes.c_void_p, dp]
         lib.DFT_ScfTailGram.argtypes = [ctypes.c_void_p, dp]
         lib.DFT_ScfTailLastError.argtypes = [ctypes.c_void_p]
@@ -73,6 +75,7 @@ class ScfTail:
         slot = self.hist[-1]
         hist = (ctypes.c_int * len(self.hist))(*self.hist)
         cf = None if coef is None else (ctypes.c_double * len(self.hist))(*[float(x) for x in coef])
+        self._last = (d_J, d_K, d_dm, d_cocc, d_exc)       # DFT_ScfTailMore continues this step (memory-resident rotation, status 3)
         self._check(self.lib.DFT_ScfTailStep(self._h, int(bool(rotate)), float(c_hf), float(tol), float(canon_tol), int(max_inner), slot,
                                              len(self.hist), hist, cf, d_J.data_ptr(), 0 if d_K is None else d_K.data_ptr(),
                                              d_vraw.data_ptr(), d_dm.data_ptr(), d_cocc.data_ptr(),
@@ -86,6 +89,15 @@ class ScfTail:
         """(tr(dm' Hcore), tr(dm' J)/2, -c_hf tr(dm' K)/4, |dm' - dm|, status, fixed-point steps, Jacobi sweeps, Exc)"""
         self._check(self.lib.DFT_ScfTailWait(self._h, self._out))
         o = self._out
+        more = 8
+        while int(o[4]) == STATUS_MORE:                    # above 128 functions the fixed point's steps are launches of their own,
+            d_J, d_K, d_dm, d_cocc, d_exc = self._last     # queued in advance: this many were not enough -- queue more, wait again
+            self._check(self.lib.DFT_ScfTailMore(self._h, more, d_J.data_ptr(), 0 if d_K is None else d_K.data_ptr(), d_dm.data_ptr(),
+                                                 d_cocc.data_ptr(), 0 if d_exc is None else d_exc.data_ptr()))
+            self._check(self.lib.DFT_ScfTailWait(self._h, self._out))
+            more = min(2 * more, 32)
+        if int(o[4]) == STATUS_DONE and int(o[5]) > 0:     # next time: two more than this cycle needed
+            self.lib.DFT_ScfTailSetStepsHint(self._h, min(max(int(o[5]) + 2, 3), 16))
         return o[0], o[1], o[2], o[3], int(o[4]), int(o[5]), int(o[6]), o[7]
 
     def gram(self):
