@@ -888,6 +888,33 @@ __global__ void k_rb_decide(RbState *st, double tol, int max_inner)
     st->rmax_bits = 0ULL;
 }
 
+// When the iteration has converged: Fo^T = Bt + Q^T K (tiles [0, nto^2)) and M = K^T K (the rest) from the current K -- the
+// completion's two long contractions (n_virt = hundreds), a tile per workgroup instead of nine tiles on one workgroup's waves
+__global__ __launch_bounds__(256) void k_rb_fop(const RbState *__restrict__ st, int n, int no, const double *K0, const double *K1,
+                                                const double *__restrict__ Qt, const double *__restrict__ Bt, double *__restrict__ Fo,
+                                                double *__restrict__ Pm)
+{
+    __shared__ double part[4][4][64];
+    if (!st->done || !st->ok) return;
+    const int nv = n - no, nto = (no + 15) >> 4, nt2 = nto * nto;
+    const double *K = st->cur ? K1 : K0;
+    const bool isf = (int)blockIdx.x < nt2;
+    const int tb = isf ? (int)blockIdx.x : (int)blockIdx.x - nt2, i0 = (tb / nto) << 4, j0 = (tb % nto) << 4;
+    const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+    double v[4];
+    if (isf) tile_splitk(i0, j0, no, no, nv, Qt, nv, 1, K, no, 1, part, v);
+    else     tile_splitk(i0, j0, no, no, nv, K, 1, no, K, no, 1, part, v);
+    if (threadIdx.x < 64)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = i0 + kq + 4 * r, col = j0 + li;
+            if (row < no && col < no) {
+                if (isf) Fo[row * no + col] = v[r] + Bt[row * no + col];
+                else Pm[row * no + col] = v[r];
+            }
+        }
+}
+
 __global__ void k_tail_clear_more(int *status)
 {
     if (status[0] == 3) status[0] = 0;
@@ -1000,9 +1027,11 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot_big(TailArgs a, const dou
     double *Fo = smalls, *Pm = smalls + n2o, *W1 = smalls + 2 * n2o, *Fop = smalls + 3 * n2o, *Vo = smalls + 4 * n2o, *cd = smalls + 5 * n2o,
            *Xm = smalls + 6 * n2o, *Lig = smalls + 7 * n2o, *L1g = smalls + 8 * n2o, *MX = smalls + 9 * n2o;
     // Fo^T = Bt + Q^T K (the transpose does as well: only the symmetrised G = L^-1 Fo L^-T is used), M = K^T K
-    wg_gemm(no, no, nv, Qt, nv, 1, Km, no, 1, 1.0, 1.0, Bt, no, Fo, no);
-    wg_gemm(no, no, nv, Km, 1, no, Km, no, 1, 1.0, 0.0, nullptr, 0, Pm, no);
-    __syncthreads();
+    if (mode != 2) {   // (mode 2: k_rb_fop has left both)
+        wg_gemm(no, no, nv, Qt, nv, 1, Km, no, 1, 1.0, 1.0, Bt, no, Fo, no);
+        wg_gemm(no, no, nv, Km, 1, no, Km, no, 1, 1.0, 0.0, nullptr, 0, Pm, no);
+        __syncthreads();
+    }
     QCDFT_STAMP(6);
     chol_and_inverses<TL_BIGO>(no, Pm, Lm, Li, L1);
     QCDFT_STAMP(7);
@@ -1106,13 +1135,16 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot_big(TailArgs a, const dou
     wg_gemm(no, no, no, Lig, 1, no, L1g, no, 1, -1.0, 0.0, nullptr, 0, Xm, no);
     for (int e = t; e < nk; e += TL_ROT_T) Kfix[e] = Km[e];   // wherever the iteration left K
     __syncthreads();
-    wg_gemm(nv, no, no, Kfix, no, 1, cd, no, 1, 1.0, 0.0, nullptr, 0, Kc, no);
-    wg_gemm(nv, no, no, Kfix, no, 1, Xm, no, 1, 1.0, 0.0, nullptr, 0, KXg, no);
+    if (mode != 2) {   // (mode 2: K c straight into W and K X by tile launches behind this kernel)
+        wg_gemm(nv, no, no, Kfix, no, 1, cd, no, 1, 1.0, 0.0, nullptr, 0, Kc, no);
+        wg_gemm(nv, no, no, Kfix, no, 1, Xm, no, 1, 1.0, 0.0, nullptr, 0, KXg, no);
+    }
     wg_gemm(no, no, no, Pm, no, 1, Xm, no, 1, 1.0, 0.0, nullptr, 0, MX, no);
     for (int e = t; e < n2o; e += TL_ROT_T) W[(size_t)(e / no) * n + e % no] = cd[e];
     __syncthreads();
     for (int e = t; e < n2o; e += TL_ROT_T) MX[e] += e / no == e % no ? 1.0 : 0.0;
-    for (int e = t; e < nk; e += TL_ROT_T) W[(size_t)(no + e / no) * n + e % no] = Kc[e];
+    if (mode != 2)
+        for (int e = t; e < nk; e += TL_ROT_T) W[(size_t)(no + e / no) * n + e % no] = Kc[e];
     QCDFT_STAMP(10);
 #undef QCDFT_STAMP
 }
@@ -1195,6 +1227,26 @@ __global__ void k_tail_need_exact(int *status)
 __global__ void k_tail_begin(int *status)
 {
     status[0] = 0; status[1] = 0; status[2] = 0;
+}
+
+// The memory-resident rotation's completion: the two long contractions, the single-workgroup part, K c / K X / the wide blocks of W
+void launch_big_finish(TailDev *c, const TailArgs &a)
+{
+    const int n = c->n, no = c->no, nv = n - no, nto = (no + 15) / 16, ntv = (nv + 15) / 16;
+    hipStream_t st = c->stream;
+    double *W = c->FU, *sm = c->smalls;
+    const size_t n2o = (size_t)no * no;
+    hipLaunchKernelGGL(k_rb_fop, dim3(2 * nto * nto), dim3(256), 0, st, c->state, n, no, c->Km, c->K2, c->Qm, c->Bm, sm, sm + n2o);
+    hipLaunchKernelGGL(k_tail_rot_big, dim3(1), dim3(TL_ROT_T), c->rot_lds, st, a, c->A, c->Km, c->K2, c->Kt, c->Kt2, c->Qm, c->Rm, c->Bm,
+                       c->rden, sm, W, c->eig, c->status, (long long *)(c->status + 8), c->Kfix, c->KXg, 2, c->state);
+    hipLaunchKernelGGL(k_tail_gemm, dim3(ntv * nto), dim3(256), 0, st, nv, no, no, c->Kfix, no, 1, sm + 5 * n2o, no, 1,
+                       W + (size_t)no * n, n, 1.0, 0, c->status);                                  // K c (W's lower left block)
+    hipLaunchKernelGGL(k_tail_gemm, dim3(ntv * nto), dim3(256), 0, st, nv, no, no, c->Kfix, no, 1, sm + 6 * n2o, no, 1,
+                       c->KXg, no, 1.0, 0, c->status);                                             // K X
+    hipLaunchKernelGGL(k_tail_gemm, dim3(nto * ntv), dim3(256), 0, st, no, nv, no, sm + 9 * n2o, no, 1, c->Kfix, 1, no,
+                       W + no, n, -1.0, 0, c->status);                                             // -(1 + M X) K^T
+    hipLaunchKernelGGL(k_tail_gemm, dim3(ntv * ntv), dim3(256), 0, st, nv, nv, no, c->KXg, no, 1, c->Kfix, 1, no,
+                       W + (size_t)no * n + no, n, 1.0, 1, c->status);                             // 1 + (K X) K^T
 }
 
 // `nsteps` fixed-point steps of the memory-resident rotation, three launches each (they return at once when the iteration is over)
@@ -1342,17 +1394,10 @@ int DFT_ScfTailStep(void *h, int rotate, double c_hf, double tol, double canon_t
             hipLaunchKernelGGL(k_tail_rot, dim3(1), dim3(TL_ROT_T), c->rot_lds, st, a, c->lo, c->A, c->U, c->Km, c->Rm, c->Qm, c->Bm, c->FU,
                                c->eig, c->status, stamps);
         } else {
-            const int no = c->no, nv = n - no, ntv = (nv + 15) / 16, nto = (no + 15) / 16;
-            double *W = c->FU;
             hipLaunchKernelGGL(k_tail_rot_big, dim3(1), dim3(TL_ROT_T), c->rot_lds, st, a, c->A, c->Km, c->K2, c->Kt, c->Kt2, c->Qm, c->Rm, c->Bm,
-                               c->rden, c->smalls, W, c->eig, c->status, stamps, c->Kfix, c->KXg, 1, c->state);
+                               c->rden, c->smalls, c->FU, c->eig, c->status, stamps, c->Kfix, c->KXg, 1, c->state);
             launch_big_steps(c, a, c->steps_hint);
-            hipLaunchKernelGGL(k_tail_rot_big, dim3(1), dim3(TL_ROT_T), c->rot_lds, st, a, c->A, c->Km, c->K2, c->Kt, c->Kt2, c->Qm, c->Rm, c->Bm,
-                               c->rden, c->smalls, W, c->eig, c->status, stamps, c->Kfix, c->KXg, 2, c->state);
-            hipLaunchKernelGGL(k_tail_gemm, dim3(nto * ntv), dim3(256), 0, st, no, nv, no, c->smalls + 9 * (size_t)no * no, no, 1, c->Kfix, 1, no,
-                               W + no, n, -1.0, 0, c->status);                                         // -(1 + M X) K^T
-            hipLaunchKernelGGL(k_tail_gemm, dim3(ntv * ntv), dim3(256), 0, st, nv, nv, no, c->KXg, no, 1, c->Kfix, 1, no,
-                               W + (size_t)no * n + no, n, 1.0, 1, c->status);                         // 1 + (K X) K^T
+            launch_big_finish(c, a);
         }
         hipLaunchKernelGGL(k_tail_gemm, dim3(nt * nt), dim3(256), 0, st, n, n, n, c->U, n, 1, c->FU, n, 1, c->Unew, n, 1.0, 0, c->status);   // U' = U W
     } else {
@@ -1373,18 +1418,12 @@ int DFT_ScfTailMore(void *h, int nsteps, unsigned long long d_J, unsigned long l
     if (!c || !c->big || !d_J || !d_dm || !d_cocc || nsteps < 1) return -1;
     c->err[0] = 0;
     const TailArgs a = c->last;
-    const int n = c->n, no = c->no, nv = n - no, nt = (n + 15) / 16, ntv = (nv + 15) / 16, nto = (no + 15) / 16;
+    const int n = c->n, nt = (n + 15) / 16;
     hipStream_t st = c->stream;
-    double *W = c->FU;
     const unsigned long seq = ++c->seq;
     hipLaunchKernelGGL(k_tail_clear_more, dim3(1), dim3(1), 0, st, c->status);
     launch_big_steps(c, a, nsteps);
-    hipLaunchKernelGGL(k_tail_rot_big, dim3(1), dim3(TL_ROT_T), c->rot_lds, st, a, c->A, c->Km, c->K2, c->Kt, c->Kt2, c->Qm, c->Rm, c->Bm,
-                       c->rden, c->smalls, W, c->eig, c->status, (long long *)(c->status + 8), c->Kfix, c->KXg, 2, c->state);
-    hipLaunchKernelGGL(k_tail_gemm, dim3(nto * ntv), dim3(256), 0, st, no, nv, no, c->smalls + 9 * (size_t)no * no, no, 1, c->Kfix, 1, no,
-                       W + no, n, -1.0, 0, c->status);
-    hipLaunchKernelGGL(k_tail_gemm, dim3(ntv * ntv), dim3(256), 0, st, nv, nv, no, c->KXg, no, 1, c->Kfix, 1, no,
-                       W + (size_t)no * n + no, n, 1.0, 1, c->status);
+    launch_big_finish(c, a);
     hipLaunchKernelGGL(k_tail_gemm, dim3(nt * nt), dim3(256), 0, st, n, n, n, c->U, n, 1, c->FU, n, 1, c->Unew, n, 1.0, 0, c->status);
     hipLaunchKernelGGL(k_tail_density, dim3(n), dim3(128), 0, st, a, 0, seq, c->H, (const double *)d_J, (const double *)d_K, c->U, c->Unew,
                        (double *)d_dm, (double *)d_cocc, c->epart, c->status, (const double *)d_exc, c->h_out_dev);
