@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <limits>
@@ -78,7 +79,8 @@ struct XCSolver {
     int ws_waves = 0;  // wave-specialised kernels (nao <= 128): 0 auto, 8 = 4+4 waves per workgroup, 16 = 8+8
     int occ = 0;       // DFT_ComputeXCOcc: 0 auto (occupied-orbital density step where it does fewer MFMAs), 1 always, 2 never
     int used_occ = 0;  // what the last sweep did (DFT_GetTimings names say so too)
-    int eri_sym = 0;   // 1: the caller vouches that the dense ERI is symmetric as an (N2, N2) matrix: DFT_ComputeCoulomb streams its upper triangle only
+    int eri_sym = 0;   // 1: the caller vouches that the dense ERI is symmetric as an (N2, N2) matrix: DFT_ComputeCoulomb streams its upper
+                       // triangle only; 2: ... and in each index pair, and dm = dm^T: the unique eighth only
     // A synchronous call seen before with the same pointers and sizes is replayed as one recorded HIP graph (one submission
     // instead of five launches): -1 auto = where the call is launch-bound (planes of at most GRAPH_AUTO_ELEMS doubles: H2O/def2-SVP
     // 30.4 -> 26.3 us per LDA call, 34.7 -> 32.9 GGA; Benzene/STO-3G 84.5 -> 86.0 and Benzene/def2-SVP 228.4 -> 230.6, so not there),
@@ -452,6 +454,28 @@ void jk(XCSolver *s, int nao, const double *eri, const double *dm, double *J, do
     const size_t N2 = (size_t)n * n;
     const int KB = std::max(1, std::min(n, JK_COLS / n));
     const int ncb = (n + KB - 1) / KB;
+    if (J && !K && s->eri_sym == 2 && i0 == 0 && ni == n) {   // the unique eighth only (k_j_sym8)
+        const size_t NPK = (size_t)n * (n + 1) / 2;
+        // packed columns per thread (4, 2, 1): the widest blocks that still leave more live workgroups than CUs (half of the
+        // (block, chunk) pairs are live; measured: nao 114 -> 4 (52.9 us; 1: 67.2), nao 80 -> 1 (31.5 us; 4: 41.7))
+        const int nchunk = (int)((NPK + JS8_RC - 1) / JS8_RC);
+        int cpt = 4;
+        while (cpt > 1 && (double)((NPK + 256 * cpt - 1) / (256 * cpt)) * nchunk / 2.0 < 1.2 * s->num_cu) cpt /= 2;
+        {
+            const char *ov = getenv("QCDFT_JSYM8_CPT");   // (tools/jsym_sweep.sh)
+            if (ov && (atoi(ov) == 1 || atoi(ov) == 2 || atoi(ov) == 4)) cpt = atoi(ov);
+        }
+        const int ncb8 = (int)((NPK + 256 * cpt - 1) / (256 * cpt)), nslab = nchunk + ncb8;
+        if (!reserve(s, s->jpart, sizeof(double) * (nslab + 1) * NPK, "hipMalloc(Jpart)")) return;
+        double *jp = (double *)s->jpart.p, *jpk = jp + (size_t)nslab * NPK;
+        if (cpt == 4)      hipLaunchKernelGGL((k_j_sym8<4>), dim3(ncb8, nchunk), dim3(256), 0, s->stream, n, eri, dm, jp);
+        else if (cpt == 2) hipLaunchKernelGGL((k_j_sym8<2>), dim3(ncb8, nchunk), dim3(256), 0, s->stream, n, eri, dm, jp);
+        else               hipLaunchKernelGGL((k_j_sym8<1>), dim3(ncb8, nchunk), dim3(256), 0, s->stream, n, eri, dm, jp);
+        hipLaunchKernelGGL(k_sum_slabs8, dim3((unsigned)((NPK + 31) / 32)), dim3(256), 0, s->stream, NPK, nslab, NPK, jp, jpk);
+        hipLaunchKernelGGL(k_unpack_sym, dim3((unsigned)((N2 + 255) / 256)), dim3(256), 0, s->stream, n, jpk, J);
+        hip_ok(s, hipGetLastError(), "J launch");
+        return;
+    }
     if (J && !K && s->eri_sym && i0 == 0 && ni == n) {   // upper triangle only (k_j_sym)
         const int nslab = n + ncb;
         if (!reserve(s, s->jpart, sizeof(double) * nslab * N2, "hipMalloc(Jpart)")) return;
@@ -1092,7 +1116,7 @@ int DFT_SetOption(XCSolver *s, const char *key, double value)
         DeviceGuard dg(s);
         drop_graphs(s); // recorded sweeps were launched under the old options
     }
-    if (!strcmp(key, "eri_symmetric")) { s->eri_sym = value != 0.0; return 0; }
+    if (!strcmp(key, "eri_symmetric")) { s->eri_sym = value == 2.0 ? 2 : value != 0.0; return 0; }
     if (!strcmp(key, "graph")) { s->graph = value > 0.0 ? 1 : value < 0.0 ? -1 : 0; return 0; }
     if (!strcmp(key, "quirks")) { s->quirks = value != 0.0; return 0; }
     if (!strcmp(key, "path")) { s->path = (int)value; return 0; }

@@ -184,6 +184,105 @@ __global__ __launch_bounds__(256) void k_j_sym(int n, int KB, const double *__re
     for (int j = tid; j < n; j += 256) rowpart[j] = (rp[0][j] + rp[1][j]) + (rp[2][j] + rp[3][j]);
 }
 
+// J from the EIGHTH of the ERI that is unique when (ij|kl) = (ji|kl) = (ij|lk) = (kl|ij) and dm = dm^T (option
+// "eri_symmetric" = 2): rows r = (i >= j), columns c = (k >= l), c <= r in the packed pair order P(a, b) = a (a + 1) / 2 + b.
+// An element e = eri[r][c] adds e w_c dm_c to J_r (w = 2 off the diagonal of its pair, 1 on it: the transposed pair is not
+// read) and, for c != r, e w_r dm_r to J_c.  Workgroup (b, g): packed columns [CB b, CB b + CB), packed rows [RC g, RC g + RC)
+// -- every live workgroup (rows not wholly before its columns) owns the same RC x CB elements, whatever i: a decomposition
+// by (i, column block) left the work of a workgroup proportional to i^2 and the chip to its heaviest ones (72 against 40 us).
+// Thread t owns packed columns CB b + t + 256 q -- consecutive threads on consecutive pairs, which are consecutive in
+// memory along a k-run (l = 0..k) -- column partials in registers, row sums by wave reduction, sixteen loads in flight.
+// Slabs of packed J: g = 0..nchunk-1 column partials, nchunk + b row partials.  172 MB instead of 1.35 GB at Benzene/def2-SVP.
+constexpr int JS8_RC = 64;
+template <int CPT>   // packed columns per thread: 4, 2 or 1
+__global__ __launch_bounds__(256) void k_j_sym8(int n, const double *__restrict__ eri, const double *__restrict__ dm,
+                                                double *__restrict__ Jpart)
+{
+    constexpr int CB = 256 * CPT, RPT = 16 / CPT;
+    __shared__ double rp[4][JS8_RC];
+    const size_t N2 = (size_t)n * n;
+    const int NPK = n * (n + 1) / 2, nchunk = (NPK + JS8_RC - 1) / JS8_RC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, g = blockIdx.y;
+    const int pbase = b * CB, r0 = g * JS8_RC, r1 = min(NPK, r0 + JS8_RC);   // rows [r0, r1)
+    double *colpart = Jpart + (size_t)g * NPK + pbase;
+    double *rowpart = Jpart + (size_t)(nchunk + b) * NPK + r0;
+    int pk[CPT];
+    size_t off[CPT];
+    double dw[CPT], ja[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        ja[q] = 0.0;
+        pk[q] = pbase + tid + 256 * q;
+        int k = (int)((sqrt(8.0 * (double)pk[q] + 1.0) - 1.0) * 0.5);
+        while (k * (k + 1) / 2 > pk[q]) --k;
+        while ((k + 1) * (k + 2) / 2 <= pk[q]) ++k;
+        const int l = pk[q] - k * (k + 1) / 2;
+        const bool valid = pk[q] < NPK;
+        off[q] = valid ? (size_t)k * n + l : 0;
+        dw[q] = valid ? dm[(size_t)k * n + l] * (k != l ? 2.0 : 1.0) : 0.0;
+        if (!valid) pk[q] = 0x7FFFFFFF;   // never <= a row's pair index
+    }
+    if (pbase >= r1) {   // every column of the block lies beyond every row of the chunk
+#pragma unroll
+        for (int q = 0; q < CPT; ++q)
+            if (pbase + tid + 256 * q < NPK) colpart[tid + 256 * q] = 0.0;
+        for (int j = tid; j < r1 - r0; j += 256) rowpart[j] = 0.0;
+        return;
+    }
+    // (i, j) of the chunk's first row
+    int ri = (int)((sqrt(8.0 * (double)r0 + 1.0) - 1.0) * 0.5);
+    while (ri * (ri + 1) / 2 > r0) --ri;
+    while ((ri + 1) * (ri + 2) / 2 <= r0) ++ri;
+    int rj = r0 - ri * (ri + 1) / 2;
+    for (int P0 = r0; P0 < r1; P0 += RPT) {
+        double e[RPT][CPT], dr[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int P = P0 + u;
+            const bool live = P < r1;
+            const double *row = eri + ((size_t)ri * n + rj) * N2;
+            dr[u] = live ? dm[(size_t)ri * n + rj] * (ri != rj ? 2.0 : 1.0) : 0.0;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) e[u][q] = (live && pk[q] <= P) ? row[off[q]] : 0.0;
+            if (live) { if (++rj > ri) { ++ri; rj = 0; } }   // the next pair
+        }
+        double racc[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int P = P0 + u;
+            racc[u] = 0.0;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                if (pk[q] < P) ja[q] = fma(e[u][q], dr[u], ja[q]);        // (rows past the chunk carry zeros)
+                racc[u] = fma(e[u][q], dw[q], racc[u]);                   // (e = 0 beyond the row's own pair)
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) racc[u] = row16_sum(racc[u]);
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const double tot = (__shfl(racc[u], 0, 64) + __shfl(racc[u], 16, 64)) + (__shfl(racc[u], 32, 64) + __shfl(racc[u], 48, 64));
+            if (lane == 0 && P0 + u < r1) rp[wave][P0 + u - r0] = tot;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CPT; ++q)
+        if (pbase + tid + 256 * q < NPK) colpart[tid + 256 * q] = ja[q];
+    __syncthreads();
+    for (int j = tid; j < r1 - r0; j += 256) rowpart[j] = (rp[0][j] + rp[1][j]) + (rp[2][j] + rp[3][j]);
+}
+
+// J[i][j] = J[j][i] = Jp[P(max, min)]
+__global__ void k_unpack_sym(int n, const double *__restrict__ Jp, double *__restrict__ J)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)n * n) return;
+    const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
+    const int a = i > j ? i : j, c = i > j ? j : i;
+    J[e] = Jp[(size_t)a * (a + 1) / 2 + c];
+}
+
 // out[e] = sum_s part[s*stride + e] in a fixed order: 32 elements x 8 slab groups per block.
 __global__ __launch_bounds__(256) void k_sum_slabs8(size_t nelem, int nslab, size_t stride,
                                                     const double *__restrict__ part,

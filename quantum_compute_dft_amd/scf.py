@@ -368,8 +368,13 @@ class HipBackend:
                 self.d_eri = torch.as_tensor(np.ascontiguousarray(inp.eri.reshape(nao * nao, nao * nao)[rlo:rhi]), dtype=f64, device=self.dev)
             # (ij|kl) = (kl|ij): when the matrix in HBM really is symmetric (checked here, once) and only J is wanted, the Coulomb
             # pass streams its upper triangle alone -- half the bytes of dft_solver.cu:550-555's GEMV, which is all a J build costs
+            # ... and when it is symmetric in each index pair too, (ij|kl) = (ji|kl) = (ij|lk), the unique eighth alone (k_j_sym8;
+            # the loop's dm = cocc cocc^T is symmetric bit for bit)
             if world == 1 and self.functional != "B3LYP" and self.d_eri is not None and bool(torch.equal(self.d_eri, self.d_eri.T)):
-                self.solver.set_option("eri_symmetric", 1)
+                e4 = self.d_eri.view(nao, nao, nao * nao)
+                eightfold = bool(torch.equal(e4, e4.transpose(0, 1)))
+                self.solver.set_option("eri_symmetric", 2 if eightfold else 1)
+                del e4
         else:  # factorised J/K (DFT_ComputeJKFactorized): Cholesky vectors stay resident instead of the ERI
             if getattr(inp, "chol_range", None) is not None:      # inputs.build(world > 1) handed over this rank's slice only
                 self.d_chol = torch.as_tensor(inp.chol, dtype=f64, device=self.dev)

@@ -483,11 +483,13 @@ def test_direct_sweep_without_resident_ao_planes(dev, fn, xc_type):
 def test_scf_in_direct_ao_mode_matches_the_resident_mode(dev):
     from quantum_compute_dft_amd import inputs, scf
     inp = inputs.build("H2O", "def2-svp", 3, verbose=False)
-    r0 = scf.run_scf(inp, scf.HipBackend(inp, "GGA"), "GGA", log=None)
+    # converged well past the driver's thresholds: the two modes differ by the summation order of Exc (1e-13), and a loop stopped at
+    # |dE| < 1e-8 keeps whatever such a difference has grown to (1.9e-10 was seen)
+    r0 = scf.run_scf(inp, scf.HipBackend(inp, "GGA"), "GGA", log=None, conv_e=1e-11, conv_dm=1e-9)
     be = scf.HipBackend(inp, "GGA", ao_mode="direct", ao_chunk=8192)
     assert be.d_ao is None and be.d_gr is None
-    r1 = scf.run_scf(inp, be, "GGA", log=None)
-    assert r0["converged"] and r1["converged"] and r0["cycles"] == r1["cycles"]
+    r1 = scf.run_scf(inp, be, "GGA", log=None, conv_e=1e-11, conv_dm=1e-9)
+    assert r0["converged"] and r1["converged"] and abs(r0["cycles"] - r1["cycles"]) <= 1
     assert r1["E_tot"] == pytest.approx(r0["E_tot"], abs=1e-10)
 
 
@@ -701,3 +703,38 @@ def test_coulomb_from_the_upper_triangle_of_a_symmetric_eri(n):
     s.compute_coulomb(n, Ens, d, J2)
     refn = (Ens.T @ d.reshape(-1)).reshape(n, n)
     assert float((J2 - refn).abs().max()) <= 1e-12 * float(refn.abs().max())
+
+
+@pytest.mark.parametrize("n", [3, 24, 33, 57, 114])
+def test_coulomb_from_the_unique_eighth_of_an_eightfold_symmetric_eri(n):
+    """Option "eri_symmetric" = 2 (k_j_sym8): with (ij|kl) = (ji|kl) = (ij|lk) = (kl|ij) and dm = dm^T, J from the pairs
+    i >= j, k >= l, (kl) <= (ij) alone equals the full pass to rounding, is symmetric bit for bit and deterministic, and
+    nothing outside that eighth is read."""
+    import torch
+    import quantum_compute_dft_amd as q
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(300 + n)
+    npk = n * (n + 1) // 2
+    G = torch.randn((npk, npk), dtype=torch.float64, device=dev, generator=g)
+    G = G + G.T
+    ii, jj = torch.meshgrid(torch.arange(n, device=dev), torch.arange(n, device=dev), indexing="ij")
+    a, c = torch.maximum(ii, jj), torch.minimum(ii, jj)
+    P = (a * (a + 1) // 2 + c).reshape(-1)                        # pair index of every (i, j)
+    E = G[P][:, P].contiguous()                                   # eight-fold symmetric by construction
+    d = torch.randn((n, n), dtype=torch.float64, device=dev, generator=g); d = (d + d.T).contiguous()
+    ref = (E.T @ d.reshape(-1)).reshape(n, n)
+    s = q.DFTSolverWrapper(q.library_path(), "GGA")
+    J0 = torch.zeros((n, n), dtype=torch.float64, device=dev); J2 = torch.zeros_like(J0); J2b = torch.zeros_like(J0); J3 = torch.zeros_like(J0)
+    s.compute_coulomb(n, E, d, J0)
+    s.set_option("eri_symmetric", 2)
+    s.compute_coulomb(n, E, d, J2)
+    s.compute_coulomb(n, E, d, J2b)
+    scale = float(ref.abs().max())
+    assert float((J0 - ref).abs().max()) <= 1e-12 * scale and float((J2 - ref).abs().max()) <= 1e-12 * scale
+    assert torch.equal(J2, J2b) and torch.equal(J2, J2.T)
+    # poison everything outside the unique eighth: rows i < j, columns k < l, and pairs (kl) > (ij)
+    lowpair = (ii >= jj).reshape(-1)
+    keep = lowpair[:, None] & lowpair[None, :] & (P[None, :] <= P[:, None])
+    Ep = torch.where(keep, E, torch.full_like(E, 1e3)).contiguous()
+    s.compute_coulomb(n, Ep, d, J3)
+    assert torch.equal(J2, J3)
