@@ -467,12 +467,11 @@ void jk(XCSolver *s, int nao, const double *eri, const double *dm, double *J, do
         }
         const int ncb8 = (int)((NPK + 256 * cpt - 1) / (256 * cpt)), nslab = nchunk + ncb8;
         if (!reserve(s, s->jpart, sizeof(double) * (nslab + 1) * NPK, "hipMalloc(Jpart)")) return;
-        double *jp = (double *)s->jpart.p, *jpk = jp + (size_t)nslab * NPK;
+        double *jp = (double *)s->jpart.p;
         if (cpt == 4)      hipLaunchKernelGGL((k_j_sym8<4>), dim3(ncb8, nchunk), dim3(256), 0, s->stream, n, eri, dm, jp);
         else if (cpt == 2) hipLaunchKernelGGL((k_j_sym8<2>), dim3(ncb8, nchunk), dim3(256), 0, s->stream, n, eri, dm, jp);
         else               hipLaunchKernelGGL((k_j_sym8<1>), dim3(ncb8, nchunk), dim3(256), 0, s->stream, n, eri, dm, jp);
-        hipLaunchKernelGGL(k_sum_slabs8, dim3((unsigned)((NPK + 31) / 32)), dim3(256), 0, s->stream, NPK, nslab, NPK, jp, jpk);
-        hipLaunchKernelGGL(k_unpack_sym, dim3((unsigned)((N2 + 255) / 256)), dim3(256), 0, s->stream, n, jpk, J);
+        hipLaunchKernelGGL(k_sum_slabs8_sym, dim3((unsigned)((NPK + 31) / 32)), dim3(256), 0, s->stream, n, nslab, jp, J);
         hip_ok(s, hipGetLastError(), "J launch");
         return;
     }

@@ -235,42 +235,85 @@ __global__ __launch_bounds__(256) void k_j_sym8(int n, const double *__restrict_
     while (ri * (ri + 1) / 2 > r0) --ri;
     while ((ri + 1) * (ri + 2) / 2 <= r0) ++ri;
     int rj = r0 - ri * (ri + 1) / 2;
-    for (int P0 = r0; P0 < r1; P0 += RPT) {
-        double e[RPT][CPT], dr[RPT];
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const int P = P0 + u;
-            const bool live = P < r1;
-            const double *row = eri + ((size_t)ri * n + rj) * N2;
-            dr[u] = live ? dm[(size_t)ri * n + rj] * (ri != rj ? 2.0 : 1.0) : 0.0;
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) e[u][q] = (live && pk[q] <= P) ? row[off[q]] : 0.0;
-            if (live) { if (++rj > ri) { ++ri; rj = 0; } }   // the next pair
-        }
-        double racc[RPT];
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const int P = P0 + u;
-            racc[u] = 0.0;
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) {
-                if (pk[q] < P) ja[q] = fma(e[u][q], dr[u], ja[q]);        // (rows past the chunk carry zeros)
-                racc[u] = fma(e[u][q], dw[q], racc[u]);                   // (e = 0 beyond the row's own pair)
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) racc[u] = row16_sum(racc[u]);
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const double tot = (__shfl(racc[u], 0, 64) + __shfl(racc[u], 16, 64)) + (__shfl(racc[u], 32, 64) + __shfl(racc[u], 48, 64));
-            if (lane == 0 && P0 + u < r1) rp[wave][P0 + u - r0] = tot;
-        }
+    // two sets of RPT rows in turn: the next set's loads are in flight while this set goes through the reductions
+    double e0[RPT][CPT], d0[RPT], e1[RPT][CPT], d1[RPT];
+#define QCDFT_J8_LOAD(E, D, PBASE)                                                                         \
+    _Pragma("unroll") for (int u = 0; u < RPT; ++u) {                                                      \
+        const int P = (PBASE) + u;                                                                         \
+        const bool live = P < r1;                                                                          \
+        const double *row = eri + ((size_t)ri * n + rj) * N2;                                              \
+        D[u] = live ? dm[(size_t)ri * n + rj] * (ri != rj ? 2.0 : 1.0) : 0.0;                              \
+        _Pragma("unroll") for (int q = 0; q < CPT; ++q) E[u][q] = (live && pk[q] <= P) ? row[off[q]] : 0.0; \
+        if (live) { if (++rj > ri) { ++ri; rj = 0; } }                                                     \
     }
+#define QCDFT_J8_USE(E, D, PBASE)                                                                          \
+    {                                                                                                      \
+        double racc[RPT];                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < RPT; ++u) {                                                  \
+            const int P = (PBASE) + u;                                                                     \
+            racc[u] = 0.0;                                                                                 \
+            _Pragma("unroll") for (int q = 0; q < CPT; ++q) {                                              \
+                if (pk[q] < P) ja[q] = fma(E[u][q], D[u], ja[q]);                                          \
+                racc[u] = fma(E[u][q], dw[q], racc[u]);                                                    \
+            }                                                                                              \
+        }                                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < RPT; ++u) racc[u] = row16_sum(racc[u]);                      \
+        _Pragma("unroll") for (int u = 0; u < RPT; ++u) {                                                  \
+            const double tot = (__shfl(racc[u], 0, 64) + __shfl(racc[u], 16, 64)) + (__shfl(racc[u], 32, 64) + __shfl(racc[u], 48, 64)); \
+            if (lane == 0 && (PBASE) + u < r1) rp[wave][(PBASE) + u - r0] = tot;                           \
+        }                                                                                                  \
+    }
+    QCDFT_J8_LOAD(e0, d0, r0)
+    for (int P0 = r0;;) {
+        if (P0 + RPT < r1) { QCDFT_J8_LOAD(e1, d1, P0 + RPT) }
+        QCDFT_J8_USE(e0, d0, P0)
+        P0 += RPT;
+        if (P0 >= r1) break;
+        if (P0 + RPT < r1) { QCDFT_J8_LOAD(e0, d0, P0 + RPT) }
+        QCDFT_J8_USE(e1, d1, P0)
+        P0 += RPT;
+        if (P0 >= r1) break;
+    }
+#undef QCDFT_J8_LOAD
+#undef QCDFT_J8_USE
 #pragma unroll
     for (int q = 0; q < CPT; ++q)
         if (pbase + tid + 256 * q < NPK) colpart[tid + 256 * q] = ja[q];
     __syncthreads();
     for (int j = tid; j < r1 - r0; j += 256) rowpart[j] = (rp[0][j] + rp[1][j]) + (rp[2][j] + rp[3][j]);
+}
+
+// The packed J of k_j_sym8 from its slabs (fixed order, as k_sum_slabs8) straight into J[i][j] and J[j][i]
+__global__ __launch_bounds__(256) void k_sum_slabs8_sym(int n, int nslab, const double *__restrict__ part, double *__restrict__ J)
+{
+    __shared__ double red[256];
+    const size_t NPK = (size_t)n * (n + 1) / 2;
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const size_t e = (size_t)blockIdx.x * 32 + el;
+    double s = 0.0;
+    if (e < NPK) {
+        int k = grp;
+        for (; k + 8 * 15 < nslab; k += 8 * 16) {
+            double v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = part[(size_t)(k + 8 * q) * NPK + e];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += v[q];
+        }
+        for (; k < nslab; k += 8) s += part[(size_t)k * NPK + e];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && e < NPK) {
+        const double *p = &red[el];
+        const double tot = ((p[0] + p[32]) + (p[64] + p[96])) + ((p[128] + p[160]) + (p[192] + p[224]));
+        int a = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+        while ((size_t)a * (a + 1) / 2 > e) --a;
+        while ((size_t)(a + 1) * (a + 2) / 2 <= e) ++a;
+        const int c = (int)(e - (size_t)a * (a + 1) / 2);
+        J[(size_t)a * n + c] = tot;
+        J[(size_t)c * n + a] = tot;
+    }
 }
 
 // J[i][j] = J[j][i] = Jp[P(max, min)]
