@@ -316,16 +316,6 @@ __global__ __launch_bounds__(256) void k_sum_slabs8_sym(int n, int nslab, const 
     }
 }
 
-// J[i][j] = J[j][i] = Jp[P(max, min)]
-__global__ void k_unpack_sym(int n, const double *__restrict__ Jp, double *__restrict__ J)
-{
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (size_t)n * n) return;
-    const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
-    const int a = i > j ? i : j, c = i > j ? j : i;
-    J[e] = Jp[(size_t)a * (a + 1) / 2 + c];
-}
-
 // out[e] = sum_s part[s*stride + e] in a fixed order: 32 elements x 8 slab groups per block.
 __global__ __launch_bounds__(256) void k_sum_slabs8(size_t nelem, int nslab, size_t stride,
                                                     const double *__restrict__ part,

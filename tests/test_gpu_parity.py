@@ -705,7 +705,7 @@ def test_coulomb_from_the_upper_triangle_of_a_symmetric_eri(n):
     assert float((J2 - refn).abs().max()) <= 1e-12 * float(refn.abs().max())
 
 
-@pytest.mark.parametrize("n", [3, 24, 33, 57, 114])
+@pytest.mark.parametrize("n", [3, 24, 33, 57, 114, 131])
 def test_coulomb_from_the_unique_eighth_of_an_eightfold_symmetric_eri(n):
     """Option "eri_symmetric" = 2 (k_j_sym8): with (ij|kl) = (ji|kl) = (ij|lk) = (kl|ij) and dm = dm^T, J from the pairs
     i >= j, k >= l, (kl) <= (ij) alone equals the full pass to rounding, is symmetric bit for bit and deterministic, and
