@@ -1,21 +1,26 @@
-// The part of an SCF cycle between the Fock contributions and the next density, on the device in six launches:
-// what dft.py:212-236 does on the host with numpy (Fock assembly, DIIS, eigh(F, S), density, energy terms) and what
-// scf.py's host loop spent 0.44 of a 0.93 ms Benzene cycle on (profiles/r03_scf_host_parts.txt: transfers 0.06,
-// Fock 0.02, DIIS 0.07, occupied-subspace rotation 0.26, density + energies 0.03).  J, K and Vxc are already in HBM
-// when the cycle's kernels finish; nothing but six scalars and a status word crosses PCIe afterwards.
+// The part of an SCF cycle between the Fock contributions and the next density, on the device, as launches queued behind
+// the cycle's J / K / sweep: what dft.py:212-236 does on the host with numpy (Fock assembly, DIIS, eigh(F, S), density, energy
+// terms) and what scf.py's host loop spent 0.44 of a 0.93 ms Benzene cycle on (QCDFT_SCF_PROFILE=1: transfers 0.06, Fock 0.02,
+// DIIS 0.07, occupied-subspace rotation 0.26, density + energies 0.03).  J, K and Vxc are already in HBM when the cycle's
+// kernels finish; nothing but eight scalars and a sequence word crosses PCIe afterwards.
 //
 //   k_tail_fock     F = H + J + (V + V^T)/2 - c_hf K/2 into the DIIS ring; F c and S c (c = occupied orbitals, dm = c c^T)
 //   k_tail_err      e = F D S - S D F through the thin factors, into the ring; one new row of the DIIS Gram matrix
-//   k_tail_mix      Pulay coefficients (a <= 9 x 9 system, per workgroup), F_ext = sum c_k F_k, F_ext U
-//   k_tail_a        A = U^T (F_ext U)
-//   k_tail_rot      ONE workgroup: the rotation K (n_virt x n_occ) that block-diagonalises A, by the diagonally
-//                   preconditioned fixed point of scf.OccupiedRotation; the new S-orthonormal basis
+//   k_tail_mix      Pulay coefficients (a <= 9 x 9 system in one wave's registers, per workgroup), F_ext = sum c_k F_k
+//   k_tail_gemm x2  F_ext U and A = U^T (F_ext U): a 16 x 16 tile per workgroup, the contraction split over four waves
+//   k_tail_rot      (nao <= 128, nocc <= 32) ONE workgroup, operands in LDS: the rotation K (n_virt x n_occ) that
+//                   block-diagonalises A, by the diagonally preconditioned fixed point of scf.OccupiedRotation; then the new
+//                   S-orthonormal basis U' = U W,
 //                       U_o' = (U_o + U_v K) L^-T V,   L L^T = 1 + K^T K,   V: Jacobi rotations that make L^-1 F_o L^-T diagonal
 //                       U_v' = T + (T K) X K^T,        T = U_v - U_o K^T,   X = -L^-T (1 + L)^-1
 //                   (the Cholesky form of the completion: no eigen-decomposition of K^T K, and
 //                    (1 + K X^T K^T)(1 + K K^T)(1 + K X K^T) = 1 exactly)
+//   k_tail_rot_big  (to nao 512, nocc 64) the same with operands in memory; its fixed-point steps are launches of their own
+//                   (k_rb_qb, k_rb_r, k_rb_decide: state in memory, early-out when the iteration is over, status 3 = queue more)
+//                   and so are its long contractions (k_rb_fop, k_tail_gemm)
+//   k_tail_gemm     U' = U W
 //   k_tail_density  dm' = c' c'^T, tr(dm' H), tr(dm' J)/2, -c_hf tr(dm' K)/4, |dm' - dm|; the last workgroup adds the
-//                   row partials in a fixed order and publishes them to host-mapped memory
+//                   row partials in a fixed order and publishes them (and the sweep's Exc) to host-mapped memory
 //
 // A cycle whose rotation is refused (first-order step above 0.5, no convergence, aufbau order in doubt) or that has
 // no basis yet reports status 1 and leaves F_ext in the caller's buffer: the caller diagonalises it (LAPACK or
