@@ -16,8 +16,11 @@ OccPlan occ_plan(int nao, int nocc, bool gga)
     p.npass = (ntiles + 7) / 8;
     p.nto = (ntiles + p.npass - 1) / p.npass;
     p.nch = (nao + OC_KC - 1) / OC_KC;
-    // all of C in LDS (row-shared kernel) when two workgroups still share a CU (160 KB of LDS)
-    p.resident = p.npass == 1 && p.nto <= 4 && occ_rs_lds_bytes(p.nto, p.nch) <= 80 * 1024;
+    // all of C in LDS (row-shared kernel) when two workgroups still share a CU (160 KB of LDS); with ONE workgroup per CU
+    // (QCDFT_OCC_RES_KB=150 at nao 246, 100 KB of C) it loses to the streamed kernel: 590 against 461 us
+    size_t res_limit = 80 * 1024;
+    if (const char *e = getenv("QCDFT_OCC_RES_KB")) res_limit = (size_t)atoi(e) * 1024;   // tools/occ_time.py
+    p.resident = p.npass == 1 && p.nto <= 4 && occ_rs_lds_bytes(p.nto, p.nch) <= res_limit;
     // streamed kernels: four-wave workgroups (two per CU) up to 64 orbitals per pass -- eight waves sharing one stream of C
     // chunks halve its L2 traffic but march in lockstep: 961 against 928 us at the Anthracene/def2-TZVP shape
     p.nw = (p.resident || p.nto <= 4) ? 4 : 8;
