@@ -41,7 +41,8 @@ def _host_cycle(S, H, J, K, V, c_hf, dm, cocc, diis, rot, tol):
 
 
 @pytest.mark.parametrize("n,no,c_hf", [(30, 7, 0.0), (114, 21, 0.0), (114, 21, 0.2), (128, 32, 0.2), (17, 1, 0.0), (45, 30, 0.2),
-                                       (150, 20, 0.2), (246, 47, 0.2), (130, 64, 0.0), (300, 33, 0.0)])   # the last four: operands in memory
+                                       (150, 20, 0.2), (246, 47, 0.2), (130, 64, 0.0), (300, 33, 0.0),    # these and the next: operands in memory
+                                       (129, 32, 0.0), (127, 33, 0.2), (512, 48, 0.0), (6, 2, 0.0), (33, 32, 0.2)])
 def test_tail_steps_match_the_host_classes(n, no, c_hf):
     import torch
     dev = torch.device("cuda:0")
