@@ -283,7 +283,7 @@ void DFT_ScfTailClose(void *handle);
  * 0 = auto, 1 = always the occupied-orbital density step, 2 = never), "eri_symmetric" (0, default: DFT_ComputeCoulomb is
  * eri^T . vec(dm) for any matrix, the reference's GEMV; 1 = the caller vouches that eri is symmetric as an (nao^2, nao^2)
  * matrix, (ij|kl) = (kl|ij), as every real ERI is: only its upper triangle is read, half the bytes and half the time; 2 = ... and
- * in each index pair, (ij|kl) = (ji|kl) = (ij|lk), and dm = dm^T: only the unique eighth is read, 53 against 240 us at Benzene/def2-SVP), "graph" (the synchronous calls: -1 = auto, default:
+ * in each index pair, (ij|kl) = (ji|kl) = (ij|lk), and dm = dm^T: only the unique eighth is read, 51 against 240 us at Benzene/def2-SVP; below 48 functions both values keep the full pass), "graph" (the synchronous calls: -1 = auto, default:
  * a call repeated with the same pointers and sizes is replayed as one recorded HIP graph where it is launch-bound,
  * planes of at most 2e6 doubles; 1 = always; 0 = never.  Same kernels, same results bit for bit), "ao_pt" (grid points per workgroup of DFT_EvalAO:
  * 8, 16, or 0 = auto), "rho_rows" (grid rows per workgroup of the large-basis

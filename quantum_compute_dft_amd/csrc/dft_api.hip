@@ -454,7 +454,9 @@ void jk(XCSolver *s, int nao, const double *eri, const double *dm, double *J, do
     const size_t N2 = (size_t)n * n;
     const int KB = std::max(1, std::min(n, JK_COLS / n));
     const int ncb = (n + KB - 1) / KB;
-    if (J && !K && s->eri_sym == 2 && i0 == 0 && ni == n) {   // the unique eighth only (k_j_sym8)
+    // (below ~48 functions the whole pass is a handful of workgroups either way and the symmetric kernels' extra slab sums
+    //  cost more than their bytes save: H2O/def2-SVP 39 against 30 us)
+    if (J && !K && s->eri_sym == 2 && i0 == 0 && ni == n && n >= 48) {   // the unique eighth only (k_j_sym8)
         const size_t NPK = (size_t)n * (n + 1) / 2;
         // packed columns per thread (4, 2, 1): the widest blocks that still leave more live workgroups than CUs (half of the
         // (block, chunk) pairs are live; measured: nao 114 -> 4 (52.9 us; 1: 67.2), nao 80 -> 1 (31.5 us; 4: 41.7))
@@ -475,7 +477,7 @@ void jk(XCSolver *s, int nao, const double *eri, const double *dm, double *J, do
         hip_ok(s, hipGetLastError(), "J launch");
         return;
     }
-    if (J && !K && s->eri_sym && i0 == 0 && ni == n) {   // upper triangle only (k_j_sym)
+    if (J && !K && s->eri_sym && i0 == 0 && ni == n && n >= 48) {   // upper triangle only (k_j_sym)
         const int nslab = n + ncb;
         if (!reserve(s, s->jpart, sizeof(double) * nslab * N2, "hipMalloc(Jpart)")) return;
         double *jp = (double *)s->jpart.p;
