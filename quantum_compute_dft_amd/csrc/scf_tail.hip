@@ -81,23 +81,23 @@ struct TailDev {
     char err[256] = {0};
 };
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v)
-{
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
 // value of `v` in lane `l` (wave-uniform l), through SGPRs: no LDS crossbar
 __device__ __forceinline__ double bcast(double v, int l)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
-
+// sum over the wave, every lane gets it: DPP row sums and four lane reads (a ds_bpermute butterfly is six LDS round trips)
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v = row16_sum(v);
+    return (bcast(v, 0) + bcast(v, 16)) + (bcast(v, 32) + bcast(v, 48));
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
 // F row i into ring slot `slot`; (F c)[i, :] and (S c)[i, :].  Thread (o, q): orbital o, quarter q of the j range.
 __global__ __launch_bounds__(256) void k_tail_fock(TailArgs a, const double *__restrict__ H, const double *__restrict__ S,
                                                    const double *__restrict__ J, const double *__restrict__ Kx,
@@ -123,10 +123,16 @@ __global__ __launch_bounds__(256) void k_tail_fock(TailArgs a, const double *__r
     const int per = (n + nq - 1) / nq, j0 = q * per, j1 = min(n, j0 + per);
     double fc = 0.0, sc = 0.0;
     if (o < no)
-        for (int j = j0; j < j1; ++j) {
-            const double cj = c[j * no + o];
-            fc = fma(frow[j], cj, fc);
-            sc = fma(srow[j], cj, sc);
+        for (int jb = j0; jb < j1; jb += 16) {   // sixteen orbital coefficients in flight, then their products
+            double cj[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) cj[u] = jb + u < j1 ? c[(jb + u) * no + o] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int j = jb + u < j1 ? jb + u : j0;   // (cj = 0 past the range)
+                fc = fma(frow[j], cj[u], fc);
+                sc = fma(srow[j], cj[u], sc);
+            }
         }
     pf[q][o] = fc;
     ps[q][o] = sc;
@@ -241,7 +247,10 @@ __global__ __launch_bounds__(128) void k_tail_mix(TailArgs a, const double *__re
             for (int k = 0; k <= TL_SPACE; ++k) {
                 if (k < d && !sing) {
                     const double cand = (!used && lane < d) ? fabs(row[k]) : -1.0;
-                    const double mx = wave_max(cand);
+                    double mx = cand;                       // the candidates sit in lanes 0..8: a DPP maximum over the first 16-lane row
+                    mx = fmax(mx, dpp_mov_f64<0x128>(mx)); mx = fmax(mx, dpp_mov_f64<0x124>(mx));
+                    mx = fmax(mx, dpp_mov_f64<0x122>(mx)); mx = fmax(mx, dpp_mov_f64<0x121>(mx));
+                    mx = bcast(mx, 0);
                     if (!(mx > 0.0)) { sing = true; }
                     else {
                         const int piv = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(cand == mx)) - 1);
