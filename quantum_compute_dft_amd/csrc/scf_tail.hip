@@ -531,7 +531,7 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
 {
 #define QCDFT_STAMP(k) do { if (threadIdx.x == 0) stamps[k] = (long long)wall_clock64(); } while (0)
     // dynamic LDS: [A (n x n) during the fixed point | the completion's small matrices afterwards][K][B][Q][R] as they fit
-    extern __shared__ double dyn[];
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
     __shared__ double dd[TL_MAXN], red[TL_ROT_T / 64];
     __shared__ int flag[TL_ROT_T / 64];
     const int n = a.n, no = a.no, nv = n - no, t = threadIdx.x, nk = nv * no;
@@ -541,13 +541,19 @@ __global__ __launch_bounds__(TL_ROT_T) void k_tail_rot(TailArgs a, RotLds lo, co
     double *As = dyn;
     double *Km = lo.km >= 0 ? dyn + lo.km : Km_g, *Bm = lo.bm >= 0 ? dyn + lo.bm : Bm_g, *Qm = lo.qm >= 0 ? dyn + lo.qm : Qm_g,
            *Rm = lo.rm >= 0 ? dyn + lo.rm : Rm_g;
-    for (int e0 = 0; e0 < n * n; e0 += 8 * TL_ROT_T) {   // eight loads in flight per thread
-        double v[8];
+    {   // 16-byte loads, sixteen in flight per thread (A and the LDS region start on 16-byte boundaries)
+        const int npair = (n * n) >> 1;
+        const double2 *A2 = reinterpret_cast<const double2 *>(A);
+        double2 *As2 = reinterpret_cast<double2 *>(As);
+        for (int e0 = 0; e0 < npair; e0 += 16 * TL_ROT_T) {
+            double2 v[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = e0 + k * TL_ROT_T + t < n * n ? A[e0 + k * TL_ROT_T + t] : 0.0;
+            for (int k = 0; k < 16; ++k) v[k] = e0 + k * TL_ROT_T + t < npair ? A2[e0 + k * TL_ROT_T + t] : make_double2(0.0, 0.0);
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (e0 + k * TL_ROT_T + t < n * n) As[e0 + k * TL_ROT_T + t] = v[k];
+            for (int k = 0; k < 16; ++k)
+                if (e0 + k * TL_ROT_T + t < npair) As2[e0 + k * TL_ROT_T + t] = v[k];
+        }
+        if ((n & 1) && t == 0) As[n * n - 1] = A[n * n - 1];
     }
     __syncthreads();
     const double *Aoo = As, *Aov = As + no, *Avo = As + (size_t)no * n, *Avv = As + (size_t)no * n + no;
