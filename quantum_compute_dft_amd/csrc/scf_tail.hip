@@ -160,6 +160,12 @@ __global__ __launch_bounds__(128) void k_tail_err(TailArgs a, const double *__re
     for (int s = 0; s < TL_SPACE; ++s) gp[s] = 0.0;
     for (int j = t; j < n; j += 128) {
         double e = 0.0;
+        double eh[TL_SPACE];                          // the ring's rows: their loads go out with the orbitals' (nothing here depends on e)
+#pragma unroll
+        for (int s = 0; s < TL_SPACE; ++s) {
+            const int h = a.hist[s < a.nhist ? s : 0];
+            eh[s] = (s < a.nhist && h != a.slot) ? Eb[(size_t)h * n * n + (size_t)i * n + j] : 0.0;
+        }
 #pragma unroll
         for (int h0 = 0; h0 < TL_BIGO; h0 += 32) {   // thirty-two orbitals' loads first: one memory round trip, not n_occ of them
             if (h0 < no) {
@@ -174,14 +180,11 @@ __global__ __launch_bounds__(128) void k_tail_err(TailArgs a, const double *__re
             }
         }
         E[i * n + j] = e;
-        double eh[TL_SPACE];
 #pragma unroll
         for (int s = 0; s < TL_SPACE; ++s) {
-            const int h = a.hist[s < a.nhist ? s : 0];
-            eh[s] = s < a.nhist ? (h == a.slot ? e : Eb[(size_t)h * n * n + (size_t)i * n + j]) : 0.0;
+            const bool self = s < a.nhist && a.hist[s] == a.slot;
+            gp[s] = fma(self ? e : eh[s], e, gp[s]);
         }
-#pragma unroll
-        for (int s = 0; s < TL_SPACE; ++s) gp[s] = fma(eh[s], e, gp[s]);
     }
 #pragma unroll
     for (int s = 0; s < TL_SPACE; ++s) {
