@@ -26,15 +26,17 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdft.so")
 STAMP_PATH = LIB_PATH + ".srchash"
-SOURCES = ["dft_api.hip", "xc_occ.hip", "eri_cols.hip", "scf_tail.hip"]   # one object each, compiled in parallel, linked into libdft.so
+SOURCES = ["dft_api.hip", "xc_occ.hip", "eri_cols.hip", "scf_tail.hip", "xc_tiny.hip"]   # one object each, compiled in parallel, linked into libdft.so
 HEADERS = ["xc_functionals.hpp", "xc_kernels.hpp", "xc_ws_kernels.hpp", "xc_ws16_kernels.hpp", "xc_big_kernels.hpp",
-           "xc_occ_kernels.hpp", "xc_occ_launch.hpp", "jk_kernels.hpp", "ao_kernels.hpp", "cd_kernels.hpp", "device_util.hpp",
+           "xc_occ_kernels.hpp", "xc_occ_launch.hpp", "xc_tiny_kernels.hpp", "xc_tiny_launch.hpp", "jk_kernels.hpp", "ao_kernels.hpp", "cd_kernels.hpp", "device_util.hpp",
            os.path.join("..", "..", "include", "dft_solver.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950's register file is unified);
 # without it hipcc 7.2 can wrap every MFMA group of a loop in v_accvgpr_write/read copy storms
 # (measured on the fp64 probe: 35 -> 75 TFLOP/s, profiles/r01_mfma_f64_probe2.txt).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wall", "-Wno-unused-function"]
+# per-source additions (the reason is at the top of the source file)
+EXTRA_FLAGS = {"xc_tiny.hip": ["-mllvm", "-disable-machine-licm"]}
 RESOURCES_PATH = LIB_PATH + ".resources.json"
 
 # Register-spill guard.  Every kernel's resource usage is read from the compiler's own report
@@ -83,7 +85,7 @@ def check_spills(res):
 
 
 def source_hash(files=None, flags=None):
-    h = hashlib.sha256(" ".join(flags if flags is not None else FLAGS).encode())
+    h = hashlib.sha256((" ".join(flags if flags is not None else FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     for f in (files if files is not None else [os.path.join(CSRC, f) for f in SOURCES + HEADERS]):
         if os.path.exists(f):
             with open(f, "rb") as fh:
@@ -140,7 +142,7 @@ def build_library(force=False, verbose=False):
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         tmp = LIB_PATH + f".tmp{os.getpid()}"
         objs = [os.path.join(LIB_DIR, f"{os.path.splitext(f)[0]}.tmp{os.getpid()}.o") for f in SOURCES]
-        cmds = [[hipcc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, f), "-o", o] for f, o in zip(SOURCES, objs)]
+        cmds = [[hipcc] + FLAGS + EXTRA_FLAGS.get(f, []) + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, f), "-o", o] for f, o in zip(SOURCES, objs)]
         logs = [o + ".log" for o in objs]
         try:
             procs = []

@@ -27,6 +27,7 @@
 #include "xc_ws16_kernels.hpp"
 #include "xc_kernels.hpp"
 #include "xc_occ_launch.hpp"
+#include "xc_tiny_launch.hpp"
 
 using namespace qcdft;
 
@@ -76,6 +77,7 @@ struct XCSolver {
     int rho_rows = 64; // grid rows per workgroup of the large-basis rho kernel: 64 (two workgroups per CU) or 128
     int sweep_order = 2; // bit 0: rho kernel walks the grid backwards, bit 1: Vxc kernel does (default: rho forward, Vxc backward)
     int dbg = 0;       // diagnostics only (ablations of the sixteen-wave kernels: 1 = no plane loads, 2 = no MFMAs)
+    int tiny = -1;     // one-pass sweep kernel for nao <= 32 (xc_tiny_kernels.hpp): -1 auto (where it is faster, tiny_pays()), 0 off, 1 on
     int ws_waves = 0;  // wave-specialised kernels (nao <= 128): 0 auto, 8 = 4+4 waves per workgroup, 16 = 8+8
     int occ = 0;       // DFT_ComputeXCOcc: 0 auto (occupied-orbital density step where it does fewer MFMAs), 1 always, 2 never
     int used_occ = 0;  // what the last sweep did (DFT_GetTimings names say so too)
@@ -241,9 +243,12 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     // Occupied-orbital density step: 16 nch nocc_tiles MFMAs per 16 grid rows (8 for LDA) against 4 NT^2 through the
     // full matrix; taken when it does clearly fewer (the two kernels run at similar matrix-pipe efficiency), on the
     // production path only.
+    // Small bases: the whole sweep in one kernel (planes below 4 GiB: one buffer descriptor each)
+    const bool tiny = s->path == 0 && s->tiny != 0 && nao <= TINY_MAX_NAO && (double)ngrid * nao * 8.0 < 4294967296.0 &&
+                      (s->tiny > 0 || tiny_pays(s->num_cu, nao, ngrid));
     OccPlan oplan;
     bool use_occ = false;
-    if (cocc && s->path == 0 && s->occ != 2) {
+    if (cocc && s->path == 0 && s->occ != 2 && !tiny) {
         oplan = occ_plan(nao, nocc, gga);
         use_occ = s->occ == 1 || oplan.mfma_occ <= 0.85 * oplan.mfma_full;
     }
@@ -284,6 +289,8 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
         nslab = (int)(8 * per_xcd);
         chunk = (ngrid + nslab - 1) / nslab;
         chunk = ((chunk + BG_BK - 1) / BG_BK) * BG_BK;
+    } else if (tiny) {
+        nslab = tiny_workgroups(s->num_cu, s->type == SOLVER_LDA ? 0 : s->type == SOLVER_GGA ? 1 : 2, nao, ngrid);
     } else if (fast) {
         const long ntile = (ngrid + WS_ROWS - 1) / WS_ROWS;
         nslab = (int)std::min<long>(s->num_cu, ntile); // one persistent, wave-specialised workgroup per CU
@@ -293,7 +300,7 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
         chunk = ((chunk + 31) / 32) * 32;
         nslab = (int)((ngrid + chunk - 1) / chunk);
     }
-    const long nxb = (ngrid + 255) / 256;
+    const long nxb = tiny ? nslab : (ngrid + 255) / 256; // Exc partials: one per workgroup of the kernel that evaluates the functional
     const size_t ng = (size_t)ngrid;
 
     if (!reserve(s, s->dsym, sizeof(double) * NP * NP, "hipMalloc(Dsym)") ||
@@ -316,6 +323,11 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
                  *gz = gga ? ao_grad + 2 * ng * nao : nullptr;
     hipStream_t st = s->stream;
 
+    if (tiny) {
+        ScopedTimer t(s, "sweep_tiny");
+        launch_sweep_tiny(st, nslab, s->type == SOLVER_LDA ? 0 : s->type == SOLVER_GGA ? 1 : 2, ngrid, nao, ao, gx, gy, gz, dm, w,
+                          slabs, partial, s->quirks);
+    }
     if (use_occ) {
         ScopedTimer t(s, "rho_occ");
         if (!reserve(s, s->occ_cp, sizeof(double) * oplan.cp_doubles, "hipMalloc(packed cocc)")) return false;
@@ -324,12 +336,12 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
                                       rho, grad, sigma), "occupied-orbital density launch"))
             return false;
     }
-    if (!fast && !use_occ) { // the wave-specialised rho kernel symmetrises D in its prologue
+    if (!fast && !use_occ && !tiny) { // the wave-specialised rho kernel symmetrises D in its prologue
         ScopedTimer t(s, "sym_dm");
         dim3 b(16, 16), g(NP / 16, NP / 16);
         hipLaunchKernelGGL(k_sym_dm, g, b, 0, st, nao, NP, dm, Dp);
     }
-    if (!use_occ) {
+    if (!use_occ && !tiny) {
         ScopedTimer t(s, "rho");
         const int vec16 = (nao % 2 == 0) && ((((uintptr_t)ao | (uintptr_t)gx | (uintptr_t)gy | (uintptr_t)gz) & 15) == 0);
         if (fast && ws16) {
@@ -368,14 +380,14 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
             else     hipLaunchKernelGGL(k_rho_valu<false>, g, dim3(256), 0, st, ngrid, nao, NP, ao, gx, gy, gz, Dp, rho, grad, sigma);
         }
     }
-    {
+    if (!tiny) {
         ScopedTimer t(s, "xc_points");
         dim3 g((unsigned)nxb);
         if (s->type == SOLVER_LDA)      hipLaunchKernelGGL(k_xc_points<0>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
         else if (s->type == SOLVER_GGA) hipLaunchKernelGGL(k_xc_points<1>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
         else                            hipLaunchKernelGGL(k_xc_points<2>, g, dim3(256), 0, st, ngrid, rho, sigma, grad, w, coef, partial, s->quirks);
     }
-    {
+    if (!tiny) {
         ScopedTimer t(s, "vxc");
         const int vec16 = (nao % 2 == 0) && ((((uintptr_t)ao | (uintptr_t)gx | (uintptr_t)gy | (uintptr_t)gz) & 15) == 0);
         if (fast && ws16) {
@@ -1128,6 +1140,7 @@ int DFT_SetOption(XCSolver *s, const char *key, double value)
     if (!strcmp(key, "sweep_order")) { s->sweep_order = (int)value & 3; return 0; }
     if (!strcmp(key, "dbg")) { s->dbg = (int)value; return 0; }
     if (!strcmp(key, "occ")) { s->occ = value == 1.0 ? 1 : value == 2.0 ? 2 : 0; return 0; }
+    if (!strcmp(key, "tiny")) { s->tiny = value > 0.0 ? 1 : value < 0.0 ? -1 : 0; return 0; }
     if (!strcmp(key, "ws_waves")) { s->ws_waves = value == 16.0 ? 16 : value == 8.0 ? 8 : 0; return 0; }
     if (!strcmp(key, "rho_rows")) { s->rho_rows = value == 128.0 ? 128 : 64; return 0; }
     if (!strcmp(key, "ao_pt")) { s->ao_pt = value == 16.0 ? 16 : value == 8.0 ? 8 : 0; return 0; }

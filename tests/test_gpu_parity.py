@@ -363,7 +363,9 @@ def test_device_resident_scf_matches_the_host_loop(dev, fn, eri_mode):
     assert r_r["converged"] and abs(r_r["cycles"] - r_h["cycles"]) <= 3 and be_r.occ_solver.stats["rotated"] >= 3
     assert r_r["E_tot"] == pytest.approx(r_h["E_tot"], abs=1e-9)
     assert np.abs(r_r["dm"] - r_h["dm"]).max() < 1e-7
-    assert r_h["converged"] and r_d["converged"] and abs(r_h["cycles"] - r_d["cycles"]) <= 1
+    # conv_e = 1e-11 Ha sits at the rounding floor of the Exc sum (1e-13 relative of ~10 Ha): the two loops reach the XC sweep
+    # through different entry points (dm / orbitals), whose sums differ in the last bits, so the LAST cycles differ
+    assert r_h["converged"] and r_d["converged"] and abs(r_h["cycles"] - r_d["cycles"]) <= 3
     assert r_d["E_tot"] == pytest.approx(r_h["E_tot"], abs=1e-9)
     assert r_d["E_xc"] == pytest.approx(r_h["E_xc"], abs=1e-9)
     assert np.abs(r_d["dm"] - r_h["dm"]).max() < 1e-7
