@@ -19,7 +19,7 @@ names = ["LDA", "GGA", "B3LYP"]
 while time.time() < t_end:
     kind = rng.integers(0, 10)
     if kind < 6:   # XC sweep
-        xc = int(rng.integers(0, 3)); nao = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 24, 33, 64, 80, 113, 114, 127, 128, 129, 130, 160, 200, 257]))
+        xc = int(rng.integers(0, 3)); nao = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 24, 31, 32, 33, 64, 80, 113, 114, 127, 128, 129, 130, 160, 200, 257]))
         ngrid = int(rng.choice([1, 5, 15, 16, 17, 31, 100, 255, 256, 257, 1000, 2049, 4097, 9000]))
         if nao * ngrid > 1.2e6: ngrid = max(1, int(1.2e6 // nao))
         path = int(rng.choice([0, 0, 0, 1, 2])); quirks = int(rng.integers(0, 2))
@@ -34,6 +34,7 @@ while time.time() < t_end:
         s = q.DFTSolverWrapper(q.library_path(), names[xc]); s.set_option("path", path); s.set_option("quirks", quirks)
         if rng.random() < 0.5: s.set_option("rho_rows", 128)
         if rng.random() < 0.3: s.set_option("ws_waves", 16)
+        if nao <= 32 and rng.random() < 0.4: s.set_option("tiny", int(rng.choice([0, 1])))   # the one-pass kernel forced on / off (default: auto)
         s.set_option("sweep_order", int(rng.integers(0, 4)))
         d_v = torch.full((nao, nao), 3.0, dtype=torch.float64, device=dev)
         if occ_call:
