@@ -25,7 +25,9 @@ Output = ONE JSON line on rank 0 (metric grid-points/s).  `roofline` is the WHOL
          Anthracene B3LYP/def2-TZVP-shaped basis (converged energies as checksums); `scf_iteration*_synthetic` the same
          loop body on synthetic operands with eigh(F, S) every cycle (the reference's loop; round 1's legs);
          `scf_benzene_real` / `scf_anthracene_def2svp_real` the driver's whole SCF on the real molecules (energy as checksum; the
-         second one sharded over the N ranks); `k_build` the factorised exact exchange on the fp64 matrix cores.
+         second one sharded over the N ranks); `k_build` the factorised exact exchange on the fp64 matrix cores; `small_basis` us per
+         synchronous call at bases of at most 32 functions (H2O/def2-SVP ... shapes): default options against the one-pass kernel
+         forced on / off (option `tiny`).
 The headline is measured first and its line is complete before any extra leg starts; the legs run under a watchdog
          (`--legs-seconds`) and a leg that fails or hangs only costs its own member (`legs_note` says so).
 """
@@ -282,6 +284,38 @@ def pmc_traffic(workload, kernels):
     if not per:
         return None
     return {"per_kernel": per, "mfma_utilisation": mfma, "covered": sorted(per), "source": ", ".join(sorted(set(src)))}
+
+
+def small_basis_leg(lib_path, dev, reps=200, rounds=5):
+    """Synchronous DFT_ComputeXC at small bases (BASELINE configs[0]'s class of molecule: H2O/def2-SVP has 24 functions and
+    34 310 grid points): us per call of the default options against the one-pass kernel forced on / off (option `tiny`,
+    csrc/xc_tiny_kernels.hpp) on synthetic planes of the named shapes.  Median of `rounds` timed bursts of `reps` calls."""
+    out = {"unit": "us per synchronous DFT_ComputeXC call", "statistic": f"median of {rounds} bursts of {reps} calls"}
+    for name, xc, ngrid, nao in (("h2o_def2svp_lda", "LDA", 34310, 24), ("h2o_def2svp_gga", "GGA", 34310, 24),
+                                 ("h2o_sto3g_gga", "GGA", 34310, 7), ("ch4_sto3g_gga", "GGA", 56000, 9),
+                                 ("nh3_def2svp_b3lyp", "B3LYP", 45000, 29), ("h2o2_sto3g_b3lyp", "B3LYP", 46000, 12),
+                                 ("small_basis_large_grid_gga", "GGA", 300000, 32)):
+        dm, ao, gr, w, _ = synth(ngrid, nao, xc != "LDA", dev, SEED)
+        row = {"ngrid": ngrid, "nao": nao, "functional": xc}
+        for label, tiny in (("default", None), ("four_launches", 0), ("one_pass", 1)):
+            s = q.DFTSolverWrapper(lib_path, xc)
+            if tiny is not None:
+                s.set_option("tiny", tiny)
+            v = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
+            for _ in range(30):
+                e = s.compute_xc(ngrid, nao, dm, ao, w, v, gr)
+            ts = []
+            for _ in range(rounds):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(reps):
+                    e = s.compute_xc(ngrid, nao, dm, ao, w, v, gr)
+                torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / reps)
+            row[label] = 1e6 * float(np.median(ts))
+            row["exc_" + label] = e
+        out[name] = row
+        del ao, gr
+    torch.cuda.empty_cache()
+    return out
 
 
 def ao_sweep_leg(lib_path, dev, reps=6, burst=10):
@@ -835,6 +869,7 @@ def main():
             if world == 1:
                 dm, ao, gr, w, cocc = synth(ngrid, nao, xc != "LDA", dev, SEED + rank)   # the same inputs again for the legs below
                 put("ao_sweep", ao_sweep_leg(lib_path, dev))
+                put("small_basis", small_basis_leg(lib_path, dev))
                 # ms/SCF-iter of the BASELINE metric = the driver's own loop on the real molecules (energies as checksums)
                 real = scf_real_leg(lib_path, dev)
                 put("scf_benzene_real", real)
