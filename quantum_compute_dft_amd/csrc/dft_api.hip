@@ -245,7 +245,7 @@ bool xc_sweep(XCSolver *s, long ngrid, int nao, const double *dm, const double *
     // production path only.
     // Small bases: the whole sweep in one kernel (planes below 4 GiB: one buffer descriptor each)
     const bool tiny = s->path == 0 && s->tiny != 0 && nao <= TINY_MAX_NAO && (double)ngrid * nao * 8.0 < 4294967296.0 &&
-                      (s->tiny > 0 || tiny_pays(s->num_cu, nao, ngrid));
+                      (s->tiny > 0 || tiny_pays(s->num_cu, s->type == SOLVER_LDA ? 0 : s->type == SOLVER_GGA ? 1 : 2, nao, ngrid));
     OccPlan oplan;
     bool use_occ = false;
     if (cocc && s->path == 0 && s->occ != 2 && !tiny) {

@@ -39,17 +39,20 @@ int tiny_workgroups(int num_cu, int type, int nao, long ngrid)
     return (int)std::max<long>(1, std::min<long>(cap, (ntile + TN_WAVES - 1) / TN_WAVES));
 }
 
-// Where the one-pass kernel is the faster call (tools/tiny_time.py scan, profiles/r03_tiny_scan.txt): one column tile
-// (nao <= 16) at every grid size measured (0.73-0.93 of the four launches); two column tiles while every CU holds at
-// most one workgroup (one sub-tile per wave, 0.92-0.95) and again from four times that many points (0.79-0.96 at
-// 150-300 k), where halving the plane traffic pays.  In between, the second sub-tile of a few waves sets the time of
-// the whole launch (1.02-1.10 at 34 k points, 0.93-1.03 at 50-100 k) and the four launches stay.
-bool tiny_pays(int num_cu, int nao, long ngrid)
+// Where the one-pass kernel is the faster call (tools/tiny_time.py scan / band, profiles/r03_tiny_scan.txt,
+// r03_tiny_band.txt).  One column tile (nao <= 16): at every grid size measured (0.73-0.93 of the four launches).
+// Two column tiles: the kernel's time is a staircase in rounds of R = 16 points x 8 waves x n_CU (one sub-tile per
+// wave of one workgroup per CU; 32 768 points on 256 CUs) -- 0.80-0.85 at exactly R, 1.00-1.06 at R + 232, where the
+// second sub-tile of a few waves costs a whole second chain -- while the four launches grow smoothly.  GGA / B3LYP (one
+// workgroup per CU) lose by at most 4 % between R and 1.3 R and win by 2-17 % from there on (0.83-0.86 at 2 R, 0.86-0.92
+// at 3.7 R, 0.79-0.93 at 9 R); LDA (two workgroups per CU, which slow each other) loses by 0-15 % up to 2 R and wins
+// from 2.4 R.
+bool tiny_pays(int num_cu, int type, int nao, long ngrid)
 {
     if (nao > TN_MAX_NAO) return false;
     if (nao <= 16) return true;
-    const long one_round = (long)num_cu * TN_WAVES * 16;
-    return ngrid <= one_round || ngrid >= 4 * one_round;
+    const double R = (double)num_cu * TN_WAVES * 16;
+    return (double)ngrid <= R || (double)ngrid >= (type == 0 ? 2.2 : 1.3) * R;
 }
 
 void launch_sweep_tiny(hipStream_t st, int nwg, int type, long ngrid, int nao, const double *ao, const double *gx,

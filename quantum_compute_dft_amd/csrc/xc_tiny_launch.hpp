@@ -7,10 +7,11 @@ namespace qcdft {
 
 constexpr int TINY_MAX_NAO = 32;
 
+// type everywhere: 0 LDA, 1 GGA, 2 B3LYP
 // option tiny = -1 (auto): the sizes at which the one-pass kernel beats rho -> xc_points -> vxc -> reduce
-bool tiny_pays(int num_cu, int nao, long ngrid);
+bool tiny_pays(int num_cu, int type, int nao, long ngrid);
 
-// workgroups (= Vxc slabs = Exc partials) of a launch over `ngrid` points; type as below
+// workgroups (= Vxc slabs = Exc partials) of a launch over `ngrid` points
 int tiny_workgroups(int num_cu, int type, int nao, long ngrid);
 
 // type 0 LDA, 1 GGA, 2 B3LYP (slabs come out as M + M^T); `slabs` holds nwg * nao * nao doubles, `partial` nwg

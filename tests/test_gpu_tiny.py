@@ -130,16 +130,17 @@ def test_bitwise_reproducible_and_graph_replay(dev):
 
 
 def test_auto_rule(dev):
-    """Default option: one column tile always; two column tiles up to one sub-tile per wave of a workgroup per CU and
-    from four times that many points (xc_tiny.hip::tiny_pays)."""
+    """Default option (xc_tiny.hip::tiny_pays): one column tile always; two column tiles up to R = one sub-tile per wave of
+    one workgroup per CU, and again from 1.3 R (GGA, B3LYP) / 2.2 R (LDA) -- right above R the four launches are faster."""
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    one_round = ncu * 8 * 16
-    for nao, ngrid, want in ((16, one_round + 5000, True), (7, 1000, True), (24, one_round - 7, True), (24, one_round + 16, False),
-                             (32, 2 * one_round, False), (32, 4 * one_round, True), (33, 1000, False)):
+    R = ncu * 8 * 16
+    for xc_type, nao, ngrid, want in ((1, 16, R + 5000, True), (1, 7, 1000, True), (1, 24, R - 7, True), (1, 24, R + 16, False),
+                                      (1, 32, int(1.25 * R), False), (2, 32, int(1.35 * R), True), (0, 24, int(1.35 * R), False),
+                                      (0, 24, int(2.1 * R), False), (0, 32, int(2.3 * R), True), (1, 32, 4 * R, True), (1, 33, 1000, False)):
         _, dm, ao, gr, w = inputs(ngrid, nao, seed=1)
-        s = _solver(1, profile=1)
-        _run(s, 1, dm, ao, gr, w, dev)
-        assert ("sweep_tiny" in _timing_names(s)) == want, (nao, ngrid)
+        s = _solver(xc_type, profile=1)
+        _run(s, xc_type, dm, ao, gr, w, dev)
+        assert ("sweep_tiny" in _timing_names(s)) == want, (xc_type, nao, ngrid)
 
 
 def test_occupied_entry_takes_the_one_pass_kernel(dev):

@@ -1,7 +1,8 @@
 """Synchronous DFT_ComputeXC at small bases: the one-pass kernel (option tiny, csrc/xc_tiny_kernels.hpp) against the
 four-launch path, as plain launches and as a recorded graph; wall time per call and the per-kernel event times.
 usage: python tools/tiny_time.py [h2o h2o_gga h2o_b3lyp nh3 big_grid ...]
-       python tools/tiny_time.py scan      (default graph option, a grid of sizes: where the one-pass kernel pays)"""
+       python tools/tiny_time.py scan      (default graph option, a grid of sizes: where the one-pass kernel pays)
+       python tools/tiny_time.py band      (the same, 17-32 functions around one sub-tile per wave slot)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,10 +12,12 @@ SHAPES = {"h2o": ("LDA", 34310, 24), "h2o_gga": ("GGA", 34310, 24), "h2o_b3lyp":
           "h2_sto3g": ("GGA", 22000, 2), "ch4_sto3g": ("GGA", 56000, 9), "nh3_gga": ("GGA", 45000, 29),
           "big_grid": ("GGA", 600000, 24), "big_grid_b3lyp": ("B3LYP", 600000, 32), "big_grid_lda16": ("LDA", 600000, 16)}
 dev = torch.device("cuda:0")
-if sys.argv[1:] == ["scan"]:
+if sys.argv[1:] in (["scan"], ["band"]):
+    band = sys.argv[1] == "band"      # the sizes right above one sub-tile per wave slot, two column tiles only
     for xc in ("LDA", "GGA", "B3LYP"):
-        for nao in (8, 16, 24, 32):
-            for ngrid in (20000, 34310, 50000, 70000, 100000, 150000, 300000):
+        for nao in ((24, 32) if band else (8, 16, 24, 32)):
+            for ngrid in ((30000, 32768, 33000, 36000, 40000, 44000, 48000, 56000, 64000, 80000, 120000) if band else
+                          (20000, 34310, 50000, 70000, 100000, 150000, 300000)):
                 g = torch.Generator(device=dev); g.manual_seed(1)
                 ao = 0.4 * torch.randn((ngrid, nao), dtype=torch.float64, device=dev, generator=g)
                 gr = 0.3 * torch.randn((3, ngrid, nao), dtype=torch.float64, device=dev, generator=g) if xc != "LDA" else None
