@@ -288,7 +288,7 @@ void DFT_ScfTailClose(void *handle);
  * planes of at most 2e6 doubles; 1 = always; 0 = never.  Same kernels, same results bit for bit), "tiny" (bases of at most 32 functions: -1 = auto, default: the
  * whole sweep -- density, functional, Vxc contraction of a 16-point sub-tile -- in ONE kernel plus the slab sum where that is
  * the faster call: at most 16 functions at any grid size, 17-32 functions up to R = 16 points per wave of one workgroup per CU
- * (32 768 points on 256 CUs) and from 1.3 R (GGA, B3LYP) / 2.2 R (LDA); 1 = whenever nao <= 32; 0 = never.  Results agree with the four-launch path to the
+ * (32 768 points on 256 CUs) and from 1.3 R; 1 = whenever nao <= 32; 0 = never.  Results agree with the four-launch path to the
  * rounding of the sums, not bit for bit), "ao_pt" (grid points per workgroup of DFT_EvalAO:
  * 8, 16, or 0 = auto), "rho_rows" (grid rows per workgroup of the large-basis
  * density kernel: 64, default, or 128).  Returns 0 if the key is known. */

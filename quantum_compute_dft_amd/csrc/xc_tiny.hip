@@ -17,42 +17,32 @@ namespace qcdft {
 
 static_assert(TINY_MAX_NAO == TN_MAX_NAO, "host and kernel limits");
 
-template <int NT, int TYPE, bool SYM> static int resident_per_cu()
+// ONE workgroup per CU, the sub-tile loop takes the rest.  The registers would let 3 / 2 workgroups of the LDA variants
+// share a CU (78 / 118 VGPRs; 512 threads are two waves on every SIMD), but a second workgroup does not start beside the
+// first: the 13 extra workgroups of a 269-workgroup launch began 11.6 us after the others, when those had finished
+// (tools/tiny_phase_probe.hip, profiles/r03_tiny_phase_probe.txt) -- a second dispatch round that pays the staging of
+// the density matrix again and starts without the loop's prefetch.  Capped at one per CU the LDA kernel at 17-32
+// functions went from 1.05-1.15 to 0.91-1.01 of the four launches between 33 k and 56 k points; the variants at
+// <= 16 functions measure the same either way (profiles/r03_tiny_scan_one_per_cu.txt against r03_tiny_scan.txt).
+int tiny_workgroups(int num_cu, int /*type*/, int /*nao*/, long ngrid)
 {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sweep_tiny<NT, TYPE, SYM>, TN_THREADS, 0) != hipSuccess || n < 1) n = 1;
-    return n;
-}
-
-// Every workgroup of the launch is resident at once (a second dispatch round would pay the staging of the density
-// matrix again and start without the prefetch of the sub-tile loop): the occupancy of the variant decides -- 512-thread
-// workgroups put two waves on each SIMD, so 3 / 2 / 1 / 1 workgroups per CU at 78 / 118 / 135-140 / 197-201 VGPRs.
-int tiny_workgroups(int num_cu, int type, int nao, long ngrid)
-{
-    static int per_cu[2][3] = {{0, 0, 0}, {0, 0, 0}};
-    const int nt = nao <= 16 ? 0 : 1, ty = type < 0 || type > 2 ? 2 : type;
-    if (!per_cu[nt][ty])
-        per_cu[nt][ty] = nt == 0 ? (ty == 0 ? resident_per_cu<1, 0, false>() : ty == 1 ? resident_per_cu<1, 1, false>() : resident_per_cu<1, 2, true>())
-                                 : (ty == 0 ? resident_per_cu<2, 0, false>() : ty == 1 ? resident_per_cu<2, 1, false>() : resident_per_cu<2, 2, true>());
     const long ntile = (ngrid + 15) / 16;
-    const long cap = (long)std::min(per_cu[nt][ty], 2) * num_cu;
-    return (int)std::max<long>(1, std::min<long>(cap, (ntile + TN_WAVES - 1) / TN_WAVES));
+    return (int)std::max<long>(1, std::min<long>(num_cu, (ntile + TN_WAVES - 1) / TN_WAVES));
 }
 
-// Where the one-pass kernel is the faster call (tools/tiny_time.py scan / band, profiles/r03_tiny_scan.txt,
-// r03_tiny_band.txt).  One column tile (nao <= 16): at every grid size measured (0.73-0.93 of the four launches).
+// Where the one-pass kernel is the faster call (tools/tiny_time.py scan / band, profiles/r03_tiny_scan*.txt,
+// r03_tiny_band*.txt).  One column tile (nao <= 16): at every grid size measured (0.73-0.93 of the four launches).
 // Two column tiles: the kernel's time is a staircase in rounds of R = 16 points x 8 waves x n_CU (one sub-tile per
-// wave of one workgroup per CU; 32 768 points on 256 CUs) -- 0.80-0.85 at exactly R, 1.00-1.06 at R + 232, where the
-// second sub-tile of a few waves costs a whole second chain -- while the four launches grow smoothly.  GGA / B3LYP (one
-// workgroup per CU) lose by at most 4 % between R and 1.3 R and win by 2-17 % from there on (0.83-0.86 at 2 R, 0.86-0.92
-// at 3.7 R, 0.79-0.93 at 9 R); LDA (two workgroups per CU, which slow each other) loses by 0-15 % up to 2 R and wins
-// from 2.4 R.
-bool tiny_pays(int num_cu, int type, int nao, long ngrid)
+// wave; 32 768 points on 256 CUs) -- 0.80-0.85 at exactly R, 0.98-1.06 at R + 232, where the second sub-tile of a few
+// waves costs a second chain (+7 us, tiny_phase_probe) -- while the four launches grow smoothly: between R and 1.3 R it
+// loses by up to 4 % (GGA, B3LYP) or ties (LDA), from 1.3 R on it wins by 2-17 % (0.83-0.86 at 2 R, 0.86-0.92 at 3.7 R,
+// 0.79-0.93 at 9 R).
+bool tiny_pays(int num_cu, int /*type*/, int nao, long ngrid)
 {
     if (nao > TN_MAX_NAO) return false;
     if (nao <= 16) return true;
     const double R = (double)num_cu * TN_WAVES * 16;
-    return (double)ngrid <= R || (double)ngrid >= (type == 0 ? 2.2 : 1.3) * R;
+    return (double)ngrid <= R || (double)ngrid >= 1.3 * R;
 }
 
 void launch_sweep_tiny(hipStream_t st, int nwg, int type, long ngrid, int nao, const double *ao, const double *gx,

@@ -32,6 +32,19 @@
 
 namespace qcdft {
 
+// tools/tiny_phase_probe.hip defines QCDFT_TINY_STAMPS: lane 0 of every wave leaves 100 MHz time stamps at the phase
+// boundaries of its FIRST sub-tile (8 per wave).  Not compiled into libdft.so.
+#ifdef QCDFT_TINY_STAMPS
+__device__ unsigned long long *g_tiny_stamps;
+#define TINY_STAMP(i, drain)                                                                                         \
+    do {                                                                                                                \
+        if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
+        if (first_pass && lane == 0) g_tiny_stamps[((size_t)blockIdx.x * TN_WAVES + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define TINY_STAMP(i, drain) do { } while (0)
+#endif
+
 constexpr int TN_THREADS = 512;
 constexpr int TN_WAVES = TN_THREADS / 64;
 constexpr int TN_MAX_NAO = 32;
@@ -58,6 +71,8 @@ __global__ __launch_bounds__(TN_THREADS) void k_sweep_tiny(long ngrid, int nao,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long ntile = (ngrid + 15) / 16;
     const long plane = ngrid * (long)nao;
+    [[maybe_unused]] bool first_pass = true;
+    TINY_STAMP(0, false);
     const __amdgpu_buffer_rsrc_t r0 = plane_rsrc(ao, plane), r1 = plane_rsrc(GRAD ? gx : ao, plane),
                                  r2 = plane_rsrc(GRAD ? gy : ao, plane), r3 = plane_rsrc(GRAD ? gz : ao, plane),
                                  rw = plane_rsrc(w, ngrid);
@@ -129,6 +144,7 @@ __global__ __launch_bounds__(TN_THREADS) void k_sweep_tiny(long ngrid, int nao,
         }
     }
     __syncthreads();
+    TINY_STAMP(1, false);
 
     for (; tile < ntile; tile += stride) {
         const long g = tile * 16 + lk + 4 * rr;
@@ -137,6 +153,7 @@ __global__ __launch_bounds__(TN_THREADS) void k_sweep_tiny(long ngrid, int nao,
             if (4 * ks + lk >= nao) af[ks] = 0.0;
         mask_planes();
         const double wt_now = wt;
+        TINY_STAMP(2, true);
 
         // X = AO . Ds
         d4 x[NT];
@@ -172,6 +189,7 @@ __global__ __launch_bounds__(TN_THREADS) void k_sweep_tiny(long ngrid, int nao,
                 d3 = rr == r ? a3 : d3;
             }
         }
+        TINY_STAMP(3, true);
         // the functional at row lk + 4 rr, on lanes li < 4
         xc::PointXC p = {0.0, 0.0, 0.0, 0.0, 0.0};
         if (li < 4 && g < ngrid) {
@@ -185,6 +203,7 @@ __global__ __launch_bounds__(TN_THREADS) void k_sweep_tiny(long ngrid, int nao,
             }
             esum += wt_now * p.exc;
         }
+        TINY_STAMP(4, true);
         // V += Q^T P, k-step r = rows lk + 4r
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -203,6 +222,8 @@ __global__ __launch_bounds__(TN_THREADS) void k_sweep_tiny(long ngrid, int nao,
 #pragma unroll
                 for (int tb = 0; tb < NT; ++tb) acc[ta][tb] = mfma_f64(q[ta], p0[r][tb], acc[ta][tb]);
         }
+        TINY_STAMP(5, true);
+        first_pass = false;
         if (tile + stride < ntile) issue_tile(tile + stride);
     }
 
@@ -229,6 +250,8 @@ __global__ __launch_bounds__(TN_THREADS) void k_sweep_tiny(long ngrid, int nao,
                 for (int r = 0; r < 4; ++r) M[(16 * ta + lk + 4 * r) * LDM + 16 * tb + li] += acc[ta][tb][r];
     }
     __syncthreads();
+    first_pass = true;
+    TINY_STAMP(6, false);
     double *slab = slabs + (size_t)blockIdx.x * nao * nao;
     constexpr int SL = NCOL * LDM;
     for (int e = tid; e < nao * nao; e += TN_THREADS) {
@@ -242,6 +265,7 @@ __global__ __launch_bounds__(TN_THREADS) void k_sweep_tiny(long ngrid, int nao,
             slab[e] = mab;
         }
     }
+    TINY_STAMP(7, true);
     if (tid == 0) partial[blockIdx.x] = ((es[0] + es[1]) + (es[2] + es[3])) + ((es[4] + es[5]) + (es[6] + es[7]));
 }
 

@@ -61,7 +61,7 @@ def _timing_names(s):
 
 
 # every AO width class (one and two column tiles, odd and even, the tile edges 15/16/17 and 31/32), grids below one
-# sub-tile, ragged, more sub-tiles than waves in flight (two workgroups per CU x 8 waves x 16 points = 65 536)
+# sub-tile, ragged, more sub-tiles than waves in flight (one workgroup per CU x 8 waves x 16 points = 32 768)
 SHAPES = [(1, 1), (1, 5), (7, 3), (15, 2), (16, 16), (17, 15), (33, 17), (96, 5), (257, 13), (1000, 16), (1025, 17),
           (4097, 24), (3001, 31), (2000, 32), (34310, 24), (70001, 7), (150017, 19)]
 
@@ -131,12 +131,12 @@ def test_bitwise_reproducible_and_graph_replay(dev):
 
 def test_auto_rule(dev):
     """Default option (xc_tiny.hip::tiny_pays): one column tile always; two column tiles up to R = one sub-tile per wave of
-    one workgroup per CU, and again from 1.3 R (GGA, B3LYP) / 2.2 R (LDA) -- right above R the four launches are faster."""
+    one workgroup per CU, and again from 1.3 R -- right above R the four launches are faster."""
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     R = ncu * 8 * 16
     for xc_type, nao, ngrid, want in ((1, 16, R + 5000, True), (1, 7, 1000, True), (1, 24, R - 7, True), (1, 24, R + 16, False),
-                                      (1, 32, int(1.25 * R), False), (2, 32, int(1.35 * R), True), (0, 24, int(1.35 * R), False),
-                                      (0, 24, int(2.1 * R), False), (0, 32, int(2.3 * R), True), (1, 32, 4 * R, True), (1, 33, 1000, False)):
+                                      (1, 32, int(1.25 * R), False), (2, 32, int(1.35 * R), True), (0, 24, int(1.2 * R), False),
+                                      (0, 32, int(1.35 * R), True), (1, 32, 4 * R, True), (1, 33, 1000, False)):
         _, dm, ao, gr, w = inputs(ngrid, nao, seed=1)
         s = _solver(xc_type, profile=1)
         _run(s, xc_type, dm, ao, gr, w, dev)
