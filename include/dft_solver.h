@@ -287,8 +287,8 @@ void DFT_ScfTailClose(void *handle);
  * a call repeated with the same pointers and sizes is replayed as one recorded HIP graph where it is launch-bound,
  * planes of at most 2e6 doubles; 1 = always; 0 = never.  Same kernels, same results bit for bit), "tiny" (bases of at most 32 functions: -1 = auto, default: the
  * whole sweep -- density, functional, Vxc contraction of a 16-point sub-tile -- in ONE kernel plus the slab sum where that is
- * the faster call: at most 16 functions at any grid size, 17-32 functions up to R = 16 points per wave of one workgroup per CU
- * (32 768 points on 256 CUs) and from 1.3 R; 1 = whenever nao <= 32; 0 = never.  Results agree with the four-launch path to the
+ * the faster call, which it is at every size measured (0.71-1.00 of the four launches, 20 k-300 k points: profiles/r03_tiny_scan_final.txt);
+ * 1 = whenever nao <= 32; 0 = never.  Results agree with the four-launch path to the
  * rounding of the sums, not bit for bit), "ao_pt" (grid points per workgroup of DFT_EvalAO:
  * 8, 16, or 0 = auto), "rho_rows" (grid rows per workgroup of the large-basis
  * density kernel: 64, default, or 128).  Returns 0 if the key is known. */

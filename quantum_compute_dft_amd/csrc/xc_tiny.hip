@@ -30,19 +30,14 @@ int tiny_workgroups(int num_cu, int /*type*/, int /*nao*/, long ngrid)
     return (int)std::max<long>(1, std::min<long>(num_cu, (ntile + TN_WAVES - 1) / TN_WAVES));
 }
 
-// Where the one-pass kernel is the faster call (tools/tiny_time.py scan / band, profiles/r03_tiny_scan*.txt,
-// r03_tiny_band*.txt).  One column tile (nao <= 16): at every grid size measured (0.73-0.93 of the four launches).
-// Two column tiles: the kernel's time is a staircase in rounds of R = 16 points x 8 waves x n_CU (one sub-tile per
-// wave; 32 768 points on 256 CUs) -- 0.80-0.85 at exactly R, 0.98-1.06 at R + 232, where the second sub-tile of a few
-// waves costs a second chain (+7 us, tiny_phase_probe) -- while the four launches grow smoothly: between R and 1.3 R it
-// loses by up to 4 % (GGA, B3LYP) or ties (LDA), from 1.3 R on it wins by 2-17 % (0.83-0.86 at 2 R, 0.86-0.92 at 3.7 R,
-// 0.79-0.93 at 9 R).
-bool tiny_pays(int num_cu, int /*type*/, int nao, long ngrid)
+// Where the one-pass kernel is the faster call (tools/tiny_time.py scan / band on the final kernel,
+// profiles/r03_tiny_scan_final.txt, r03_tiny_band_final.txt): everywhere it applies -- 0.71-0.93 of the four launches at
+// nao <= 16, 0.75-1.00 at 17-32 functions, 20 k to 300 k points, all three functionals.  (Until a partial last round of
+// sub-tiles was dealt one per CU instead of eight to the first workgroups, the sizes right above one sub-tile per wave,
+// 32.8-42.6 k points, lost by up to 6 % and the rule excluded them: r03_tiny_band.txt.)
+bool tiny_pays(int /*num_cu*/, int /*type*/, int nao, long /*ngrid*/)
 {
-    if (nao > TN_MAX_NAO) return false;
-    if (nao <= 16) return true;
-    const double R = (double)num_cu * TN_WAVES * 16;
-    return (double)ngrid <= R || (double)ngrid >= 1.3 * R;
+    return nao <= TN_MAX_NAO;
 }
 
 void launch_sweep_tiny(hipStream_t st, int nwg, int type, long ngrid, int nao, const double *ao, const double *gx,

@@ -4,7 +4,7 @@
 // the four-launch form lasts about as long as its dispatch and the call is a chain of launch latencies
 // (profiles/r03_graph_time.txt: 30 us, 26 us replayed as a graph); the planes are also read once instead of twice.
 //
-// A wave owns sub-tiles tile = wave_id, wave_id + nwaves, ...  Per sub-tile:
+// A wave owns sub-tiles wave * n_WG + workgroup (+ 8 n_WG per round).  Per sub-tile:
 //   1. the four planes land in registers in the RESULT layout of v_mfma_f64_16x16x4 (lane (lk, li) holds rows
 //      lk + 4r, r = 0..3, column 16t + li): rows of 128 contiguous bytes;
 //   2. X = AO . Ds on the matrix pipe (A fragments AO[g0 + li][4ks + lk] are a second, L1-served read of the AO
@@ -125,7 +125,10 @@ __global__ __launch_bounds__(TN_THREADS) void k_sweep_tiny(long ngrid, int nao,
         wt = buf_load_f64(rw, (unsigned)(lk + 4 * rr) * 8u, (unsigned)(tile * 16) * 8u);
     };
     const long stride = (long)gridDim.x * TN_WAVES;
-    long tile = (long)blockIdx.x * TN_WAVES + wave;
+    // round s hands tile s * stride + wave * gridDim.x + blockIdx.x to this wave: a partial last round goes to wave 0 of
+    // every workgroup, then wave 1 ... -- one extra sub-tile per CU, on a SIMD whose other wave has finished -- instead of
+    // to all eight waves of the first few workgroups
+    long tile = (long)wave * gridDim.x + blockIdx.x;
     if (tile < ntile) issue_tile(tile); // in flight while the density matrix is staged
     // Ds = (D + D^T)/2 as B fragments, zero outside nao x nao, straight from the caller's matrix; kept in LDS
     // (the same 16 NT^2 values per lane for every wave; in registers they cost 8 NT^2 VGPRs through the functional)

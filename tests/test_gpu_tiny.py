@@ -130,17 +130,19 @@ def test_bitwise_reproducible_and_graph_replay(dev):
 
 
 def test_auto_rule(dev):
-    """Default option (xc_tiny.hip::tiny_pays): one column tile always; two column tiles up to R = one sub-tile per wave of
-    one workgroup per CU, and again from 1.3 R -- right above R the four launches are faster."""
+    """Default option (xc_tiny.hip::tiny_pays): the one-pass kernel wherever it applies (nao <= 32), also right above one
+    sub-tile per wave of one workgroup per CU (R) where a partial second round is dealt one sub-tile per CU."""
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     R = ncu * 8 * 16
-    for xc_type, nao, ngrid, want in ((1, 16, R + 5000, True), (1, 7, 1000, True), (1, 24, R - 7, True), (1, 24, R + 16, False),
-                                      (1, 32, int(1.25 * R), False), (2, 32, int(1.35 * R), True), (0, 24, int(1.2 * R), False),
-                                      (0, 32, int(1.35 * R), True), (1, 32, 4 * R, True), (1, 33, 1000, False)):
+    for xc_type, nao, ngrid, want in ((1, 16, R + 5000, True), (1, 7, 1000, True), (1, 24, R - 7, True), (1, 24, R + 16, True),
+                                      (2, 32, int(1.25 * R), True), (0, 24, int(1.2 * R), True), (1, 32, 4 * R, True),
+                                      (1, 33, 1000, False), (0, 40, R, False)):
         _, dm, ao, gr, w = inputs(ngrid, nao, seed=1)
+        exc_ref, v_ref = oracle.compute_xc(xc_type, dm, ao, w, gr if xc_type else None, omp=True)
         s = _solver(xc_type, profile=1)
-        _run(s, xc_type, dm, ao, gr, w, dev)
+        exc, v = _run(s, xc_type, dm, ao, gr, w, dev)
         assert ("sweep_tiny" in _timing_names(s)) == want, (xc_type, nao, ngrid)
+        _check(exc, v, exc_ref, v_ref)      # partial second and later rounds of sub-tiles against the oracle as well
 
 
 def test_occupied_entry_takes_the_one_pass_kernel(dev):
