@@ -160,3 +160,20 @@ def test_occupied_entry_takes_the_one_pass_kernel(dev):
             torch.cuda.synchronize()
             assert "sweep_tiny" in _timing_names(s)
             _check(exc, d_v.cpu().numpy(), exc_ref, v_ref)
+
+
+def test_scf_energy_with_and_without_the_one_pass_kernel(dev):
+    """H2O/def2-SVP (24 functions, 34 310 points: every sweep of the SCF goes through k_sweep_tiny by default), converged far
+    below the driver's thresholds: same energies as with the four-launch sweep."""
+    from quantum_compute_dft_amd import inputs as inp_mod, scf
+    inp = inp_mod.build("H2O", "def2-svp", 3, verbose=False)
+    for fn in ("LDA", "GGA"):
+        res = []
+        for tiny in (1, 0):
+            be = scf.HipBackend(inp, fn)
+            be.solver.set_option("tiny", tiny)
+            res.append(scf.run_scf(inp, be, fn, log=None, conv_e=1e-11, conv_dm=1e-9))
+        assert res[0]["converged"] and res[1]["converged"]
+        assert res[0]["E_tot"] == pytest.approx(res[1]["E_tot"], abs=1e-9)
+        assert res[0]["E_xc"] == pytest.approx(res[1]["E_xc"], abs=1e-9)
+        assert np.abs(res[0]["dm"] - res[1]["dm"]).max() < 1e-7
